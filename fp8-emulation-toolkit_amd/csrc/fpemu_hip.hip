@@ -1,0 +1,416 @@
+// fpemu_hip.hip -- streaming cast + amax kernels for MI355X (gfx950) and the C ABI of
+// include/fpemu_hip.h.  Written for CDNA4 only: 64-lane wavefronts, 16-byte (dwordx4)
+// non-temporal global accesses, no LDS in the cast (nothing is reused), one launch per call,
+// no host synchronisation, no allocation.
+//
+// Replaces, behind the same operator boundary, the reference's
+//   fpemu_cuda_forward + *_Kernel   mpemu/pytquant/hip/fpemu_kernels.hip:254-1392
+//   fpemu_common_function           mpemu/pytquant/cpp/fpemu_impl.cpp:1866-2009
+// (one element per thread, 4-byte accesses, hipDeviceSynchronize per call, racy global RNG).
+//
+// Memory layout: buffers are flat and contiguous.  A wavefront iteration covers one
+// "superblock" = 4 slots x 64 lanes x 16 B = 4 KiB; lane L of the wave touches the four
+// 16-byte vectors {slot*64 + L}.  Every load/store instruction of a wave is therefore one
+// fully coalesced 1 KiB segment.  Elements past the last whole superblock (and whole buffers
+// whose pointers are not 16-byte aligned) go through a 4-byte-per-lane path in the same launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fpemu_hip.h"
+#include "fpemu_device.hpp"
+
+using namespace fpemu;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kBlock = 256;         // 4 wavefronts
+constexpr int kWavesPerBlock = 4;
+constexpr int kDefaultMaxBlocks = 256 * 8;  // 256 CUs x 8 resident 256-thread blocks
+
+int g_max_blocks = 0;
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+struct CastParams {
+  float scale;                // host-provided scale (ignored when amax_bits != nullptr)
+  float rcp;                  // (float)(1.0/(double)scale), computed on the host
+  const uint32_t *amax_bits;  // device word; non-null: derive scale on device
+  float flt_max;
+  int clamp;
+  uint64_t seed, offset;
+  uint64_t elem_base;         // global index of element 0 of this buffer
+};
+
+template <int DT> struct Storage;
+template <> struct Storage<FPEMU_F32> { static constexpr unsigned V = 4; using elem = float; };
+template <> struct Storage<FPEMU_F16> { static constexpr unsigned V = 8; using elem = uint16_t; };
+template <> struct Storage<FPEMU_BF16> { static constexpr unsigned V = 8; using elem = uint16_t; };
+
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  uint32_t u = f2u(f);
+  const uint32_t rn = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+  const uint32_t nan = (u >> 16) | 0x0040u;
+  return ((u & 0x7FFFFFFFu) > 0x7F800000u) ? nan : rn;
+}
+
+template <int DT> __device__ __forceinline__ float load_elem16(uint32_t b) {
+  if constexpr (DT == FPEMU_F16) return h_to_f32(b);
+  else return u2f(b << 16);
+}
+template <int DT> __device__ __forceinline__ uint32_t store_elem16(float f) {
+  if constexpr (DT == FPEMU_F16) return f32_to_h(f);
+  else return f32_to_bf16_bits(f);
+}
+
+// Random bits for element e (0..V-1) of slot s from the lane's Philox results of this superblock.
+template <int FMT, unsigned V, int NCALLS>
+__device__ __forceinline__ uint32_t lane_noise(const Philox4 (&p)[NCALLS], unsigned slot, unsigned e) {
+  constexpr unsigned NB = noise_bytes<FMT>();
+  const unsigned pos = (slot * V + e) * NB;   // compile-time after unrolling
+  const uint32_t w = philox_word(p[pos / 16u], (pos % 16u) / 4u) >> ((pos % 4u) * 8u);
+  return w;  // consumers mask the bits they use
+}
+
+template <int FMT, int RM, int DT>
+__global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out_,
+                                                      uint64_t nsb, uint64_t n, CastParams prm) {
+  constexpr unsigned V = Storage<DT>::V;
+  constexpr uint64_t SB_ELEMS = (uint64_t)V * 64u * 4u;
+  constexpr bool SR = (RM == STOCHASTIC);
+  constexpr int NCALLS = SR ? (int)(4u * V * noise_bytes<FMT>() / 16u) : 1;
+
+  float scale = prm.scale, rcp = prm.rcp;
+  if (prm.amax_bits != nullptr) {
+    scale = scale_from_amax(*prm.amax_bits, prm.flt_max, prm.clamp != 0);
+    rcp = scale_reciprocal(scale);
+  }
+
+  const unsigned lane = threadIdx.x & 63u;
+  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  const u32x4 *in = reinterpret_cast<const u32x4 *>(in_);
+  u32x4 *out = reinterpret_cast<u32x4 *>(out_);
+  const uint64_t sb_base = prm.elem_base / SB_ELEMS;
+
+  for (uint64_t sb = wave; sb < nsb; sb += nwaves) {
+    const uint64_t v0 = sb * 256u + lane;
+    u32x4 v[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) v[s] = __builtin_nontemporal_load(&in[v0 + (uint64_t)s * 64u]);
+
+    Philox4 p[NCALLS];
+    if constexpr (SR) {
+      const uint64_t c = ((sb_base + sb) * 64u + lane) << 2;
+#pragma unroll
+      for (int k = 0; k < NCALLS; k++) p[k] = philox4x32_10(prm.seed, c | (uint64_t)k, prm.offset);
+    }
+
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if constexpr (DT == FPEMU_F32) {
+          const uint32_t rnd = SR ? lane_noise<FMT, V, NCALLS>(p, s, j) : 0u;
+          o[j] = f2u(cast_one<FMT, RM>(u2f(v[s][j]), scale, rcp, rnd));
+        } else {
+          const uint32_t w = v[s][j];
+          const uint32_t r0 = SR ? lane_noise<FMT, V, NCALLS>(p, s, 2 * j) : 0u;
+          const uint32_t r1 = SR ? lane_noise<FMT, V, NCALLS>(p, s, 2 * j + 1) : 0u;
+          const float y0 = cast_one<FMT, RM>(load_elem16<DT>(w & 0xFFFFu), scale, rcp, r0);
+          const float y1 = cast_one<FMT, RM>(load_elem16<DT>(w >> 16), scale, rcp, r1);
+          o[j] = (store_elem16<DT>(y0) & 0xFFFFu) | (store_elem16<DT>(y1) << 16);
+        }
+      }
+      __builtin_nontemporal_store(o, &out[v0 + (uint64_t)s * 64u]);
+    }
+  }
+
+  // Tail (n % superblock) and unaligned buffers (launched with nsb == 0): one element per lane
+  // per step, still coalesced, same element -> noise mapping.
+  using elem_t = typename Storage<DT>::elem;
+  const elem_t *ein = reinterpret_cast<const elem_t *>(in_);
+  elem_t *eout = reinterpret_cast<elem_t *>(out_);
+  const uint64_t tstride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = nsb * SB_ELEMS + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += tstride) {
+    uint32_t rnd = 0u;
+    if constexpr (SR) rnd = rand_bits_elem<FMT, V>(prm.seed, prm.offset, prm.elem_base + i);
+    if constexpr (DT == FPEMU_F32) {
+      eout[i] = cast_one<FMT, RM>(ein[i], scale, rcp, rnd);
+    } else {
+      eout[i] = (elem_t)store_elem16<DT>(cast_one<FMT, RM>(load_elem16<DT>(ein[i]), scale, rcp, rnd));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// amax: unsigned max over |x| bit patterns; wave64 butterfly, one LDS word per wave, one
+// device-scope atomic per block.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t m) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64);
+    m = m > o ? m : o;
+  }
+  return m;
+}
+
+template <int DT> __device__ __forceinline__ uint32_t absmax_word(uint32_t m, uint32_t w) {
+  if constexpr (DT == FPEMU_F32) {
+    const uint32_t a = w & 0x7FFFFFFFu;
+    return m > a ? m : a;
+  } else {
+    const uint32_t a = w & 0x7FFFu, b = (w >> 16) & 0x7FFFu;
+    const uint32_t c = a > b ? a : b;
+    return m > c ? m : c;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ in_, uint64_t nvec,
+                                                      uint64_t n, uint32_t *amax_bits) {
+  constexpr unsigned V = Storage<DT>::V;
+  const u32x4 *in = reinterpret_cast<const u32x4 *>(in_);
+  const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  uint32_t m = 0u;
+  uint64_t i = tid;
+  for (; i + 3u * stride < nvec; i += 4u * stride) {
+    u32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(&in[i + (uint64_t)k * stride]);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, v[k][j]);
+  }
+  for (; i < nvec; i += stride) {
+    const u32x4 v = __builtin_nontemporal_load(&in[i]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, v[j]);
+  }
+  // element tail / unaligned buffers (nvec == 0)
+  using elem_t = typename Storage<DT>::elem;
+  const elem_t *ein = reinterpret_cast<const elem_t *>(in_);
+  for (uint64_t e = nvec * V + tid; e < n; e += stride) {
+    if constexpr (DT == FPEMU_F32) m = absmax_word<DT>(m, f2u(ein[e]));
+    else m = absmax_word<DT>(m, (uint32_t)ein[e]);
+  }
+
+  m = wave_max_u32(m);
+  __shared__ uint32_t part[kWavesPerBlock];
+  if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t r = part[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; w++) r = r > part[w] ? r : part[w];
+    // storage pattern -> fp32 pattern (order preserving; NaN stays above +Inf)
+    if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
+    else if constexpr (DT == FPEMU_BF16) r = r << 16;
+    if (r != 0u) __hip_atomic_fetch_max(amax_bits, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side: dispatch tables and launch geometry.
+// ---------------------------------------------------------------------------------------------
+typedef void (*cast_fn)(const void *, void *, uint64_t, uint64_t, CastParams);
+
+template <int DT> cast_fn pick_cast(int fmt, int rm) {
+#define FPEMU_CASE(F, R) \
+  if (fmt == F && rm == R) return cast_kernel<F, R, DT>;
+  FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
+  FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
+  FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
+  FPEMU_CASE(E5M2_DAZ, RNTZ)
+  FPEMU_CASE(E4M3, RTZ) FPEMU_CASE(E4M3, RNE) FPEMU_CASE(E4M3, STOCHASTIC)
+  FPEMU_CASE(E3M4, RTZ) FPEMU_CASE(E3M4, RNE) FPEMU_CASE(E3M4, STOCHASTIC)
+  FPEMU_CASE(BF16, RTZ) FPEMU_CASE(BF16, RNE) FPEMU_CASE(BF16, STOCHASTIC)
+  FPEMU_CASE(FP16, RNE) FPEMU_CASE(FP16, STOCHASTIC)
+  FPEMU_CASE(FP16_DAZ, RNE)
+#undef FPEMU_CASE
+  return nullptr;
+}
+
+cast_fn pick_cast_dt(int dtype, int fmt, int rm) {
+  switch (dtype) {
+    case FPEMU_F32: return pick_cast<FPEMU_F32>(fmt, rm);
+    case FPEMU_F16: return pick_cast<FPEMU_F16>(fmt, rm);
+    case FPEMU_BF16: return pick_cast<FPEMU_BF16>(fmt, rm);
+    default: return nullptr;
+  }
+}
+
+unsigned elem_size(int dtype) { return dtype == FPEMU_F32 ? 4u : 2u; }
+unsigned vec_elems(int dtype) { return dtype == FPEMU_F32 ? 4u : 8u; }
+
+int max_blocks() { return g_max_blocks > 0 ? g_max_blocks : kDefaultMaxBlocks; }
+
+int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
+                const CastParams &prm, void *stream) {
+  if (n == 0) return FPEMU_OK;
+  if (in == nullptr || out == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast: null buffer");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_cast: bad dtype id");
+  cast_fn fn = pick_cast_dt(dtype, fmt, rmode);
+  if (fn == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast: format / rounding-mode pair not defined");
+  const unsigned es = elem_size(dtype);
+  if (((uintptr_t)in % es) || ((uintptr_t)out % es))
+    return fail(FPEMU_EALIGN, "fpemu_cast: buffer not aligned to its element size");
+
+  const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 256u;
+  const bool vec_ok = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (prm.elem_base % sb_elems) == 0;
+  const uint64_t nsb = vec_ok ? n / sb_elems : 0;
+  const uint64_t tail = n - nsb * sb_elems;
+  uint64_t blocks = (nsb + kWavesPerBlock - 1) / kWavesPerBlock;
+  const uint64_t tail_blocks = (tail + kBlock - 1) / kBlock;
+  if (blocks < tail_blocks) blocks = tail_blocks;
+  if (blocks > (uint64_t)max_blocks()) blocks = (uint64_t)max_blocks();
+  if (blocks == 0) blocks = 1;
+
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, in, out, nsb,
+                     n, prm);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  return FPEMU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fpemu_abi_version(void) { return FPEMU_ABI_VERSION; }
+
+const char *fpemu_last_error(void) { return g_err; }
+
+void fpemu_set_max_blocks(int mb) { g_max_blocks = mb; }
+
+int fpemu_parse_mode(const char *mode, int *fmt, int *rmode) {
+  static const struct { const char *name; int fmt, rmode; } tab[] = {
+      {"E5M2_RTZ", E5M2, RTZ},
+      {"E5M2_RNE", E5M2, RNE},
+      {"E5M2_STOCHASTIC", E5M2, STOCHASTIC},
+      {"E5M2_RNAZ", E5M2, RNAZ},
+      {"E5M2_RNTZ", E5M2, RNTZ},
+      {"E5M2_RPINF", E5M2, RPINF},
+      {"E5M2_RNINF", E5M2, RNINF},
+      {"E5M2_DAZ_RNE", E5M2_DAZ, RNE},
+      {"E5M2_DAZ_STOCHASTIC", E5M2_DAZ, STOCHASTIC},
+      {"E5M2_DAZ_RNAZ", E5M2_DAZ, RNAZ},
+      {"E5M2_DAZ_RNTZ", E5M2_DAZ, RNTZ},
+      {"FLOAT16_RNE", FP16, RNE},
+      {"FLOAT16_STOCHASTIC", FP16, STOCHASTIC},
+      {"FLOAT16_DAZ_RNE", FP16_DAZ, RNE},
+      {"BFLOAT16_RNE", BF16, RNE},
+      {"BFLOAT16_STOCHASTIC", BF16, STOCHASTIC},
+      {"E4M3_RNE", E4M3, RNE},
+      {"E4M3_STOCHASTIC", E4M3, STOCHASTIC},
+      {"E3M4_RNE", E3M4, RNE},
+      {"E3M4_STOCHASTIC", E3M4, STOCHASTIC},
+      // RTZ extensions named by the north star; not defined by the reference
+      {"E4M3_RTZ", E4M3, RTZ},
+      {"E3M4_RTZ", E3M4, RTZ},
+      {"BFLOAT16_RTZ", BF16, RTZ},
+  };
+  if (mode == nullptr || fmt == nullptr || rmode == nullptr)
+    return fail(FPEMU_EINVAL, "fpemu_parse_mode: null argument");
+  for (const auto &t : tab) {
+    if (strcmp(mode, t.name) == 0) {
+      *fmt = t.fmt;
+      *rmode = t.rmode;
+      return FPEMU_OK;
+    }
+  }
+  if (!strcmp(mode, "E4M3_IEEE_RNE") || !strcmp(mode, "E4M3_IEEE_STOCHASTIC") ||
+      !strcmp(mode, "FP4_NEAREST"))
+    return fail(FPEMU_EUNSUPPORTED, "fpemu: mode exists in the reference but is outside this build's scope");
+  return fail(FPEMU_EMODE, "fpemu: unknown mode string");
+}
+
+int fpemu_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode, float scale,
+               uint64_t seed, uint64_t offset, uint64_t elem_base, void *stream) {
+  // the reference aborts the process on scale > FLT_MAX (cpp:772-776); report it instead
+  if (scale > 3.402823466e+38f) return fail(FPEMU_EINVAL, "fpemu_cast: invalid scale factor (inf)");
+  CastParams prm;
+  prm.scale = scale;
+  prm.rcp = (float)(1.0 / (double)scale);  // cpp:714
+  prm.amax_bits = nullptr;
+  prm.flt_max = 0.f;
+  prm.clamp = 0;
+  prm.seed = seed;
+  prm.offset = offset;
+  prm.elem_base = elem_base;
+  return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
+}
+
+int fpemu_forward(const void *in, void *out, int dtype, const char *mode, uint64_t size, float scale,
+                  int block_norm, int block_size, uint64_t seed, uint64_t offset, void *stream) {
+  int fmt = 0, rmode = 0;
+  int rc = fpemu_parse_mode(mode, &fmt, &rmode);
+  if (rc != FPEMU_OK) return rc;
+  if (block_norm && block_size > 0 && (uint64_t)block_size != size && (size % (uint64_t)block_size) != 0)
+    block_norm = 0;  // cpp:2020-2025
+  if (block_norm) return fail(FPEMU_EUNSUPPORTED, "fpemu_forward: block_norm is not implemented");
+  return fpemu_cast(in, out, size, dtype, fmt, rmode, scale, seed, offset, 0, stream);
+}
+
+int fpemu_amax(const void *in, uint64_t n, int dtype, uint32_t *amax_bits, void *stream) {
+  if (n == 0) return FPEMU_OK;
+  if (in == nullptr || amax_bits == nullptr) return fail(FPEMU_EINVAL, "fpemu_amax: null argument");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_amax: bad dtype id");
+  if ((uintptr_t)in % elem_size(dtype)) return fail(FPEMU_EALIGN, "fpemu_amax: buffer not aligned");
+  const bool vec_ok = ((uintptr_t)in % 16u) == 0;
+  const uint64_t nvec = vec_ok ? n / vec_elems(dtype) : 0;
+  const uint64_t work = nvec ? nvec : n;
+  uint64_t blocks = (work + kBlock - 1) / kBlock;
+  // each thread should see >= 4 vectors before paying for the block reduction
+  if (nvec) blocks = (blocks + 3) / 4;
+  if (blocks > (uint64_t)max_blocks()) blocks = (uint64_t)max_blocks();
+  if (blocks == 0) blocks = 1;
+  void (*fn)(const void *, uint64_t, uint64_t, uint32_t *) =
+      dtype == FPEMU_F32 ? amax_kernel<FPEMU_F32>
+                         : dtype == FPEMU_F16 ? amax_kernel<FPEMU_F16> : amax_kernel<FPEMU_BF16>;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, in, nvec, n,
+                     amax_bits);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  return FPEMU_OK;
+}
+
+int fpemu_cast_scaled(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
+                      const uint32_t *amax_bits, float flt_max, int clamp, uint64_t seed,
+                      uint64_t offset, uint64_t elem_base, void *stream) {
+  if (amax_bits == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast_scaled: null amax word");
+  CastParams prm;
+  prm.scale = 1.f;
+  prm.rcp = 1.f;
+  prm.amax_bits = amax_bits;
+  prm.flt_max = flt_max;
+  prm.clamp = clamp;
+  prm.seed = seed;
+  prm.offset = offset;
+  prm.elem_base = elem_base;
+  return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
+}
+
+int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
+                              float flt_max, uint32_t *amax_ws, uint64_t seed, uint64_t offset,
+                              void *stream) {
+  if (amax_ws == nullptr) return fail(FPEMU_EINVAL, "fpemu_quantize_per_tensor: null workspace");
+  hipError_t e = hipMemsetAsync(amax_ws, 0, sizeof(uint32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  int rc = fpemu_amax(in, n, dtype, amax_ws, stream);
+  if (rc != FPEMU_OK) return rc;
+  return fpemu_cast_scaled(in, out, n, dtype, fmt, rmode, amax_ws, flt_max, 1, seed, offset, 0, stream);
+}
+
+}  // extern "C"

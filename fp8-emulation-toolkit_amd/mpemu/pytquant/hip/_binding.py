@@ -1,0 +1,200 @@
+"""ctypes binding of libfpemu_hip.so (C ABI: include/fpemu_hip.h).
+
+This is the thin host layer between torch tensors and the hand-written gfx950 kernels.  torch
+supplies device memory and the current HIP stream only; no arithmetic happens in torch here.
+There is NO fallback: if the library is missing or the tensor is not on a ROCm device the call
+raises.
+
+Stands where the reference's pybind module `fpemu_hip` stands
+(mpemu/pytquant/hip/fpemu_impl.cpp:27-53): `forward(...)` below keeps that signature.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfpemu_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+_DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+# format ids / flt_max of include/fpemu_hip.h
+FMT_E5M2, FMT_E4M3, FMT_E3M4, FMT_BF16, FMT_FP16, FMT_E5M2_DAZ, FMT_FP16_DAZ = range(7)
+STOCHASTIC = 2
+
+_ERR = {-1: ValueError, -2: ValueError, -3: NotImplementedError, -4: ValueError}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libfpemu_hip.so; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(_SO):
+            raise ImportError(
+                "libfpemu_hip.so not found at %s: build it with `make -C fp8-emulation-toolkit_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU or eager fallback" % _SO)
+        L = ctypes.CDLL(_SO)
+        u64, i32, f32, vp = ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+        L.fpemu_abi_version.restype = i32
+        L.fpemu_last_error.restype = ctypes.c_char_p
+        L.fpemu_parse_mode.restype = i32
+        L.fpemu_parse_mode.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+        L.fpemu_cast.restype = i32
+        L.fpemu_cast.argtypes = [vp, vp, u64, i32, i32, i32, f32, u64, u64, u64, vp]
+        L.fpemu_forward.restype = i32
+        L.fpemu_forward.argtypes = [vp, vp, i32, ctypes.c_char_p, u64, f32, i32, i32, u64, u64, vp]
+        L.fpemu_amax.restype = i32
+        L.fpemu_amax.argtypes = [vp, u64, i32, vp, vp]
+        L.fpemu_cast_scaled.restype = i32
+        L.fpemu_cast_scaled.argtypes = [vp, vp, u64, i32, i32, i32, vp, f32, i32, u64, u64, u64, vp]
+        L.fpemu_quantize_per_tensor.restype = i32
+        L.fpemu_quantize_per_tensor.argtypes = [vp, vp, u64, i32, i32, i32, f32, vp, u64, u64, vp]
+        L.fpemu_set_max_blocks.restype = None
+        L.fpemu_set_max_blocks.argtypes = [i32]
+        if L.fpemu_abi_version() != 1:
+            raise ImportError("libfpemu_hip.so: ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc == 0:
+        return
+    msg = lib().fpemu_last_error().decode(errors="replace")
+    if rc < 0:
+        raise _ERR.get(rc, RuntimeError)(msg)
+    raise RuntimeError("HIP error %d: %s" % (rc, msg))
+
+
+def parse_mode(mode):
+    """(fmt, rmode) ids of a reference mode string; raises ValueError for an unknown string
+    (the reference silently does nothing, cpp/fpemu_impl.cpp:1994-2000)."""
+    f, r = ctypes.c_int(), ctypes.c_int()
+    _check(lib().fpemu_parse_mode(str(mode).encode(), ctypes.byref(f), ctypes.byref(r)))
+    return f.value, r.value
+
+
+def _dtype_id(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise TypeError("fpemu: unsupported tensor dtype %s (float32, float16, bfloat16 only)" % t.dtype)
+
+
+def _require_device(t, what="input"):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "fpemu: %s must live on a ROCm device (got %s); this build has no CPU path" % (what, t.device))
+    if not t.is_contiguous():
+        raise RuntimeError("fpemu: %s must be contiguous" % what)  # hip/fpemu_impl.cpp:23-25
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+# ---- stochastic-rounding stream state: (seed, per-call offset) -----------------------------
+_seed = 0x5EED0F8E3A11
+_offset = 0
+
+
+def manual_seed(seed):
+    """Re-key the Philox stream of the stochastic modes and rewind the call counter."""
+    global _seed, _offset
+    _seed, _offset = int(seed) & (2 ** 64 - 1), 0
+
+
+def get_rng_state():
+    return _seed, _offset
+
+
+def set_rng_state(state):
+    global _seed, _offset
+    _seed, _offset = int(state[0]), int(state[1])
+
+
+def _next_offset(rmode):
+    global _offset
+    if rmode != STOCHASTIC:
+        return 0
+    o = _offset
+    _offset += 1
+    return o
+
+
+def cast_(src, dst, fmt, rmode, scale=1.0, seed=None, offset=None, elem_base=0):
+    """dst[i] = cast(src[i]); dst may be src.  Both contiguous device tensors of one dtype."""
+    _require_device(src)
+    _require_device(dst, "output")
+    if dst.dtype != src.dtype or dst.numel() != src.numel():
+        raise ValueError("fpemu: input/output mismatch")
+    if offset is None:
+        offset = _next_offset(rmode)
+    with torch.cuda.device_of(src):
+        _check(lib().fpemu_cast(src.data_ptr(), dst.data_ptr(), src.numel(), _dtype_id(src), fmt, rmode,
+                                float(scale), _seed if seed is None else seed, offset, elem_base,
+                                _stream(src)))
+    return dst
+
+
+def amax_(src, amax_bits):
+    """amax_bits (int32[1], same device, zeroed by the caller) <- max(amax_bits, bits(max|src|))."""
+    _require_device(src)
+    with torch.cuda.device_of(src):
+        _check(lib().fpemu_amax(src.data_ptr(), src.numel(), _dtype_id(src), amax_bits.data_ptr(),
+                                _stream(src)))
+    return amax_bits
+
+
+def cast_scaled_(src, dst, fmt, rmode, amax_bits, flt_max, clamp=True, seed=None, offset=None,
+                 elem_base=0):
+    _require_device(src)
+    _require_device(dst, "output")
+    if offset is None:
+        offset = _next_offset(rmode)
+    with torch.cuda.device_of(src):
+        _check(lib().fpemu_cast_scaled(src.data_ptr(), dst.data_ptr(), src.numel(), _dtype_id(src), fmt,
+                                       rmode, amax_bits.data_ptr(), float(flt_max), int(bool(clamp)),
+                                       _seed if seed is None else seed, offset, elem_base, _stream(src)))
+    return dst
+
+
+def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None):
+    """Fused amax -> device-side scale -> cast (qutils.py:282-287), no host sync."""
+    _require_device(src)
+    _require_device(dst, "output")
+    if amax_ws is None:
+        amax_ws = torch.empty(1, dtype=torch.int32, device=src.device)
+    with torch.cuda.device_of(src):
+        _check(lib().fpemu_quantize_per_tensor(src.data_ptr(), dst.data_ptr(), src.numel(),
+                                               _dtype_id(src), fmt, rmode, float(flt_max),
+                                               amax_ws.data_ptr(), _seed, _next_offset(rmode),
+                                               _stream(src)))
+    return dst
+
+
+def forward(input, mode, size, inplace, scale, block_norm=False, block_size=1):
+    """Same call as the reference's pybind `fpemu_hip.forward` (hip/fpemu_impl.cpp:27-37):
+    returns a 1-element list holding the new tensor, or `input` itself when inplace."""
+    _require_device(input)
+    if int(size) != input.numel():
+        raise ValueError("fpemu.forward: size (%d) != input.numel() (%d)" % (size, input.numel()))
+    _, rmode = parse_mode(mode)
+    out = input if inplace else torch.empty_like(input)
+    with torch.cuda.device_of(input):
+        _check(lib().fpemu_forward(input.data_ptr(), out.data_ptr(), _dtype_id(input), str(mode).encode(),
+                                   input.numel(), float(scale), int(bool(block_norm)), int(block_size),
+                                   _seed, _next_offset(rmode), _stream(input)))
+    return [out]
+
+
+backward = forward  # hip/fpemu_impl.cpp:39-49: the same function applied to a gradient

@@ -1,0 +1,310 @@
+"""mpemu.qutils -- tensor/module quantisation configs, the scale policy and the module hooks.
+
+Host-side mirror of the reference's mpemu/qutils.py for the fpemu cast path, MI355X build.
+Same names, arguments and results:
+
+  TensorQuantConfig / ModuleQuantConfig / ModuleQuantParams   qutils.py:22-214
+  fpemu_device_fn                                             qutils.py:249-261
+  quantize_tensor                                             qutils.py:264-345
+  model-config / hook helpers                                 qutils.py:351-365, 458-475, 478-660
+
+What differs underneath: every cast runs in the gfx950 HIP kernels (pytquant/hip); the
+per-tensor "max" policy computes amax, the scale and the cast on the device in one enqueue
+(no `if scale > ...` host sync, qutils.py:285); per-channel "max" does the same per channel.
+Results are bit-identical to the reference's CPU path (tests/golden/qtensor.npz).
+
+With `set_amax_process_group(group)` a per-tensor "max" cast treats the tensor as one shard
+of a larger tensor: the local amax word is all-reduced (MAX) over the group before the cast,
+so every rank derives the same scale (DESIGN.md "Multi-GPU").
+"""
+from collections import OrderedDict
+import copy
+
+import torch
+
+from .pytquant.hip import _binding as _hip
+
+_FLT_MAX = {"e5m2": 57344.0, "e4m3": 448.0, "e4m3_ieee": 240.0, "e3m4": 30.0, "fp4": 1.0}
+_FLT_MIN = {"e5m2": 1.5258789E-05, "e4m3": 1.9531250E-03, "e3m4": 1.5625000E-02, "fp4": 0.000244140625}
+
+_amax_group = None
+
+
+def set_amax_process_group(group):
+    """group: a torch.distributed process group (or None to go back to single-device scaling)."""
+    global _amax_group
+    _amax_group = group
+
+
+class TensorQuantConfig(object):
+    """Quantisation configuration of one tensor role (qutils.py:22-132)."""
+
+    def __init__(self, dtype=None, scheme=None, scaling="None", group_size=1):
+        super(TensorQuantConfig, self).__init__()
+        tokens = scaling.split("-")
+        self.dtype = dtype
+        self.scheme = scheme
+        self.scaling = "tensor" in tokens
+        self.per_channel = "channel" in tokens
+        self.scaling_method = "mean" if "mean" in tokens else "max"
+        if "int" in self.dtype:
+            self.scaling_method = "none"
+        self.fine_grained = scaling == "fine-grained"
+        self.group_size = group_size if self.fine_grained else 1
+        self.is_enabled = True
+
+        self.dtypes_all = ["e5m2", "e4m3", "e3m4", "fp4", "bfloat16", "float16"]
+        self.e5m2_modes = ["rtz", "stochastic", "rne", "rnaz", "rntz", "rpinf", "rninf",
+                           "daz_stochastic", "daz_rne", "daz_rnaz", "daz_rntz"]
+        self.e4m3_modes = ["rne", "stochastic", "rtz"]
+        self.e4m3_ieee_modes = ["ieee_rne", "ieee_stochastic"]
+        self.e4m3_all_modes = self.e4m3_modes + self.e4m3_ieee_modes
+        self.e3m4_modes = ["rne", "stochastic", "rtz"]
+        self.fp4_modes = ["nearest"]
+        self.bfloat16_modes = ["rne", "stochastic", "rtz"]
+        # the reference misspells this attribute (qutils.py:51 vs :98) so dtype "float16" raises
+        # AttributeError there; here it validates.
+        self.float16_modes = ["rne", "daz_rne", "stochastic"]
+
+        self.check_validity(dtype, scheme)
+
+    def check_validity(self, dtype, scheme):
+        if "int" in dtype:
+            return  # integers of all sizes are acceptable
+        assert dtype in self.dtypes_all, "Invalid data type, list of supported types : {}".format(self.dtypes_all)
+        allowed = {"e5m2": self.e5m2_modes, "e4m3": self.e4m3_all_modes, "e3m4": self.e3m4_modes,
+                   "fp4": self.fp4_modes, "bfloat16": self.bfloat16_modes, "float16": self.float16_modes}[dtype]
+        assert scheme in allowed, "scheme {} is not in {}".format(scheme, allowed)
+
+    def _format_key(self):
+        if self.dtype == "e4m3" and self.scheme in self.e4m3_ieee_modes:
+            return "e4m3_ieee"
+        return self.dtype
+
+    def get_flt_max(self):
+        return _FLT_MAX.get(self._format_key())
+
+    def get_flt_min(self):
+        return _FLT_MIN.get(self.dtype)
+
+    def __repr__(self):
+        how = ("per-channel" if self.per_channel else "per-tensor" if self.scaling
+               else "fine-grained" if self.fine_grained else "None")
+        return "[{}, scale: {}, method: {}]".format(self.dtype + "_" + self.scheme, how, self.scaling_method)
+
+
+class ModuleQuantConfig(object):
+    """Quantisation configuration of one module (qutils.py:137-198)."""
+
+    def __init__(self, wt_qconfig=None, iact_qconfig=None, oact_qconfig=None,
+                 wtgrad_qconfig=None, igrad_qconfig=None, ograd_qconfig=None, patch_ops=False):
+        super(ModuleQuantConfig, self).__init__()
+        self.wt_qconfig = wt_qconfig
+        self.iact_qconfig = iact_qconfig
+        self.oact_qconfig = oact_qconfig
+        self.wtgrad_qconfig = wtgrad_qconfig
+        self.igrad_qconfig = igrad_qconfig
+        self.ograd_qconfig = ograd_qconfig
+
+        self.device = 'cuda'
+        self.patch_ops = patch_ops
+        self.patch_impl = "None"
+        self.sparse_config = None
+        self.global_step = -1
+        self.bin_dump = False
+        self.tensor_stats = False
+        self.tb_writer = None
+        self.weight_master = None  # master copy of the weight (bfloat16 emulation)
+
+    def register_output_grad_hook(self, output):
+        def quantize_output_grad(grad):
+            if self.sparse_config is not None and self.sparse_config.outgrad:
+                grad.data = self.sparse_config.sparsify_outgrad_tensor(grad.data)
+            if self.ograd_qconfig is not None and self.ograd_qconfig.is_enabled:
+                grad = quantize_tensor(grad, self.ograd_qconfig, None, inplace=False)
+            return grad
+
+        if output.requires_grad:
+            output.register_hook(quantize_output_grad)
+
+    def register_weight_grad_hook(self, module):
+        def quantize_weight_grad(grad):
+            if self.sparse_config is not None and self.sparse_config.wtgrad:
+                grad.data = self.sparse_config.sparsify_wtgrad_tensor(grad.data)
+            if self.wtgrad_qconfig is not None and self.wtgrad_qconfig.is_enabled:
+                grad.data = quantize_tensor(grad.data, self.wtgrad_qconfig, None, inplace=True)
+            return grad
+
+        if type(module) in [torch.nn.Conv2d, torch.nn.Linear]:
+            if module.weight is not None and module.weight.requires_grad:
+                module.weight.register_hook(quantize_weight_grad)
+
+    def __repr__(self):
+        if self.igrad_qconfig is None:
+            return "[weights: {}, inputs: {}, output: {}]".format(
+                self.wt_qconfig, self.iact_qconfig, self.oact_qconfig)
+        return ("[weights: {}, inputs: {}, output: {}, weight_grad: {}, input_grad: {}, "
+                "output_grad: {}]").format(self.wt_qconfig, self.iact_qconfig, self.oact_qconfig,
+                                           self.wtgrad_qconfig, self.igrad_qconfig, self.ograd_qconfig)
+
+
+class ModuleQuantParams(object):
+    """Per-module quantisation parameters; the FP formats are stateless (qutils.py:204-214)."""
+
+    def __init__(self, wt_qparams=None, iact_qparams=None, oact_qparams=None,
+                 wtgrad_qparams=None, igrad_qparams=None, ograd_qparams=None):
+        super(ModuleQuantParams, self).__init__()
+        self.wt_qparams = wt_qparams
+        self.iact_qparams = iact_qparams
+        self.oact_qparams = oact_qparams
+        self.wtgrad_qparams = wtgrad_qparams
+        self.igrad_qparams = igrad_qparams
+        self.ograd_qparams = ograd_qparams
+
+
+def quantize_to_integer(tensor, mode, inplace=False):
+    """INT-n asymmetric fake quantisation in plain torch ops (qutils.py:216-247); not on the
+    fpemu cast path."""
+    lo, hi = torch.min(tensor), torch.max(tensor)
+    nbits = int(mode.split("INT")[1]) - 1
+    q_min, q_max = -1 * 2 ** nbits, (2 ** nbits) - 1
+    scale = (hi - lo) / (q_max - q_min)
+    zero_point = q_min - (lo / scale)
+    q = torch.clamp(torch.round((tensor / scale) + zero_point), q_min, q_max)
+    dq = scale * (q - zero_point)
+    if inplace is True:
+        tensor.data.copy_(dq)
+        return tensor
+    return dq
+
+
+def fpemu_device_fn(tensor, mode, inplace=True, scale=1.0):
+    """Device dispatch of one cast (qutils.py:249-261)."""
+    if "INT" in mode:
+        return quantize_to_integer(tensor, mode.split("_")[0], inplace=inplace)
+    if tensor.is_cuda:
+        from .pytquant import fpemu_cuda
+        return fpemu_cuda.FPEmuOp.apply(tensor, mode, inplace, scale)
+    from .pytquant import fpemu_cpp
+    return fpemu_cpp.FPEmuOp.apply(tensor, mode, inplace, scale)
+
+
+class _ScaledCast(torch.autograd.Function):
+    """amax -> scale -> cast entirely on the device; straight-through backward (the same
+    estimator FPEmuOp uses, pytquant/cpp/fpemu.py:68-71).  `rows` > 0 selects per-channel
+    scaling over dim 0 (one scale per row of the flattened [rows, cols] view)."""
+
+    @staticmethod
+    def forward(ctx, tensor, mode, inplace, flt_max, rows, clamp):
+        fmt, rmode = _hip.parse_mode(mode)
+        src = tensor.contiguous()
+        dst = src if inplace else torch.empty_like(src)
+        if rows:
+            _hip_quantize_rows(src, dst, fmt, rmode, flt_max, rows, clamp)
+        elif _amax_group is not None:
+            ws = torch.zeros(1, dtype=torch.int32, device=src.device)
+            _hip.amax_(src, ws)
+            torch.distributed.all_reduce(ws, op=torch.distributed.ReduceOp.MAX, group=_amax_group)
+            _hip.cast_scaled_(src, dst, fmt, rmode, ws, flt_max, clamp=clamp)
+        else:
+            _hip.quantize_per_tensor_(src, dst, fmt, rmode, flt_max)
+        if inplace:
+            if src is not tensor:
+                tensor.copy_(src)
+            ctx.mark_dirty(tensor)
+            return tensor
+        return dst
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None, None, None, None, None
+
+
+def _hip_quantize_rows(src, dst, fmt, rmode, flt_max, rows, clamp):
+    """Per-row amax/scale/cast of a contiguous [rows, cols] buffer, no host sync."""
+    s2, d2 = src.view(rows, -1), dst.view(rows, -1)
+    ws = torch.zeros(rows, dtype=torch.int32, device=src.device)
+    for r in range(rows):
+        _hip.amax_(s2[r], ws[r:r + 1])
+    for r in range(rows):
+        _hip.cast_scaled_(s2[r], d2[r], fmt, rmode, ws[r:r + 1], flt_max, clamp=clamp)
+
+
+def _mean_scale(sample, qtconfig, threshold, use_mode):
+    """The reference's "mean" policies, host-synchronising like the original
+    (qutils.py:276-281 per tensor; :294-301 / :322-327 per channel / group use torch.mode)."""
+    flat = torch.flatten(sample.detach())
+    if use_mode:
+        mean = abs(torch.mode(flat).values.data)
+    else:
+        mean = torch.mean(abs(flat))
+    flt_min = qtconfig.get_flt_min()
+    mean = abs(mean) if abs(mean) > threshold else flt_min
+    scale = 1.0
+    if abs(mean) > 0.0:
+        scale = flt_min / abs(mean)
+    return 1.0 if scale < 1.0 else scale
+
+
+def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
+    """Single entry point for quantising a tensor (qutils.py:264-345)."""
+    qtconfig.check_validity(qtconfig.dtype, qtconfig.scheme)
+    mode = qtconfig.dtype.upper()
+    if qtconfig.scheme is not None:
+        mode += "_" + qtconfig.scheme.upper()
+    on_device = tensor.is_cuda and "INT" not in mode
+
+    if qtconfig.scaling is True:
+        if qtconfig.scaling_method == "max" and on_device:
+            return _ScaledCast.apply(tensor, mode, inplace, qtconfig.get_flt_max(), 0, True)
+        scale = 1.0
+        if qtconfig.scaling_method == "mean":
+            scale = _mean_scale(tensor, qtconfig, 1e-5, use_mode=False)
+        elif qtconfig.scaling_method == "max":
+            vmax = torch.max(abs(torch.flatten(tensor.detach())))
+            scale = qtconfig.get_flt_max() / vmax
+            scale = 6.55e+04 if scale > 3.275e+04 else scale
+        return fpemu_device_fn(tensor, mode, inplace=inplace, scale=scale)
+
+    if qtconfig.per_channel is True:
+        if qtconfig.scaling_method == "max" and on_device and tensor.dim() >= 1 and tensor.shape[0] > 0:
+            # the reference loops over dim 0 and never goes through autograd for the pieces
+            q = _ScaledCast.apply(tensor.detach(), mode, inplace, qtconfig.get_flt_max(), tensor.shape[0], True)
+            return tensor if inplace else q
+        tensor_q = None if inplace else torch.zeros_like(tensor)
+        for c in range(tensor.shape[0]):
+            sub = tensor.select(0, c).detach()
+            scale = 1.0
+            if qtconfig.scaling_method == "mean":
+                scale = _mean_scale(sub, qtconfig, 1e-6, use_mode=True)
+            elif qtconfig.scaling_method == "max":
+                vmax = torch.max(abs(torch.flatten(sub)))
+                scale = qtconfig.get_flt_max() / vmax
+                scale = 6.55e+04 if scale > 3.275e+04 else scale
+            sub = fpemu_device_fn(sub, mode, inplace=False, scale=scale)
+            (tensor if inplace else tensor_q).select(0, c).data.copy_(sub)
+        return tensor if inplace else tensor_q
+
+    if qtconfig.fine_grained is True:
+        tensor_q = None if inplace else torch.zeros_like(tensor)
+        for k in range(tensor.shape[0]):
+            crs = tensor.select(0, k).detach()
+            if not inplace:
+                crs = crs.clone()
+            chunks = max(1, int(crs.shape[0] / qtconfig.group_size))
+            for sub in crs.chunk(chunks, 0):
+                if qtconfig.scaling_method == "max" and on_device and sub.is_contiguous():
+                    _ScaledCast.apply(sub, mode, True, qtconfig.get_flt_max(), 0, False)
+                    continue
+                scale = 1.0
+                if qtconfig.scaling_method == "mean":
+                    scale = _mean_scale(sub, qtconfig, 1e-6, use_mode=True)
+                elif qtconfig.scaling_method == "max":
+                    vmax = torch.max(abs(torch.flatten(sub)))
+                    scale = qtconfig.get_flt_max() / vmax
+                fpemu_device_fn(sub, mode, inplace=True, scale=scale)
+            if not inplace:
+                tensor_q.select(0, k).data.copy_(crs)
+        return tensor if inplace else tensor_q
+
+    return fpemu_device_fn(tensor, mode, inplace=inplace)

@@ -1,0 +1,131 @@
+/*
+ * fpemu_hip.h -- C ABI of libfpemu_hip.so, the MI355X (gfx950) fpemu cast.
+ *
+ * Drop-in boundary for the reference's native cast entry point: the pybind11 functions
+ * `forward` / `backward` of mpemu/pytquant/{cpp,hip}/fpemu_impl.cpp
+ *     std::vector<Tensor> (Tensor input, std::string mode, int size, bool inplace,
+ *                          float scale, bool block_norm, int block_size)
+ * (reference: pytquant/hip/fpemu_impl.cpp:27-53, pytquant/cpp/fpemu_impl.cpp:2013-2050).
+ * Here the same call is expressed with plain pointers: the caller owns every buffer, `out`
+ * may equal `in` (the reference's inplace=true), and work is enqueued on the given HIP
+ * stream without any host synchronisation or allocation.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - return value: 0 on success, a negative FPEMU_E* code for argument errors, or a positive
+ *     hipError_t value if the HIP runtime refused the launch.  fpemu_last_error() returns a
+ *     thread-local description of the last failure;
+ *   - no function here allocates, frees or synchronises.
+ */
+#ifndef FPEMU_HIP_H
+#define FPEMU_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPEMU_ABI_VERSION 1
+
+/* Storage dtype of in/out buffers. */
+enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
+
+/* Emulated target format.  One id per reference kernel:
+ *   E5M2      E5M2_Kernel        cpp/fpemu_impl.cpp:765   (scalar routine :691-763 is canonical)
+ *   E4M3      E4M3_Kernel        cpp/fpemu_impl.cpp:1135  (:1038-1133)
+ *   E3M4      E3M4_Kernel        cpp/fpemu_impl.cpp:1720  (:1624-1718)
+ *   BF16      BFLOAT16_Kernel    cpp/fpemu_impl.cpp:331   (RNE :207-232, SR :284-329)
+ *   FP16      FLOAT16_Kernel     cpp/fpemu_impl.cpp:356
+ *   E5M2_DAZ  E5M2_DAZ_Kernel    cpp/fpemu_impl.cpp:846
+ *   FP16_DAZ  FLOAT16_Kernel with no_denorm=1 (cpp:1943-1947) */
+enum {
+  FPEMU_FMT_E5M2 = 0,
+  FPEMU_FMT_E4M3 = 1,
+  FPEMU_FMT_E3M4 = 2,
+  FPEMU_FMT_BF16 = 3,
+  FPEMU_FMT_FP16 = 4,
+  FPEMU_FMT_E5M2_DAZ = 5,
+  FPEMU_FMT_FP16_DAZ = 6
+};
+
+/* Rounding mode: the reference's enum ROUNDING_MODES, cpp/fpemu_impl.cpp:15-23. */
+enum {
+  FPEMU_RTZ = 0,
+  FPEMU_RNE = 1,
+  FPEMU_STOCHASTIC = 2,
+  FPEMU_RNAZ = 3,
+  FPEMU_RNTZ = 4,
+  FPEMU_RPINF = 5,
+  FPEMU_RNINF = 6
+};
+
+/* Error codes (negative). */
+enum {
+  FPEMU_OK = 0,
+  FPEMU_EINVAL = -1,       /* null pointer, bad dtype/fmt/rmode id, non-finite scale */
+  FPEMU_EMODE = -2,        /* mode string not recognised (the reference silently no-ops) */
+  FPEMU_EUNSUPPORTED = -3, /* recognised but not built: block_norm, E4M3_IEEE_*, FP4_NEAREST */
+  FPEMU_EALIGN = -4        /* pointer not aligned to the element size */
+};
+
+int fpemu_abi_version(void);
+const char *fpemu_last_error(void);
+
+/* Mode-string dispatcher: replaces the if/else chain of fpemu_common_function
+ * (cpp/fpemu_impl.cpp:1878-2000; hip/fpemu_kernels.hip:1069-1386).  Accepts every string the
+ * reference dispatches plus the three RTZ extensions BASELINE.json names (E4M3_RTZ, E3M4_RTZ,
+ * BFLOAT16_RTZ).  Returns FPEMU_EMODE for an unknown string, FPEMU_EUNSUPPORTED for
+ * E4M3_IEEE_* and FP4_NEAREST. */
+int fpemu_parse_mode(const char *mode, int *fmt, int *rmode);
+
+/* The cast itself: out[i] = dequant(quant_fmt(in[i] * scale)) * (1/scale), i in [0, n).
+ * Replaces E5M2_Kernel / E4M3_Kernel / E3M4_Kernel / BFLOAT16_Kernel / FLOAT16_Kernel /
+ * E5M2_DAZ_Kernel (cpp/fpemu_impl.cpp:331,356,765,846,1135,1720 and their GPU twins
+ * hip/fpemu_kernels.hip:254-995).  `out == in` is the in-place form.
+ *   seed, offset : key and call counter of the Philox4x32-10 stream used by FPEMU_STOCHASTIC
+ *                  (replaces the global xoshiro state cpp:41-88 / hip:47-102);
+ *   elem_base    : global index of in[0] inside the logical tensor (sharded runs; 0 otherwise).
+ * 64-bit n: the reference's `int size` overflows at 2^31 elements. */
+int fpemu_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode, float scale,
+               uint64_t seed, uint64_t offset, uint64_t elem_base, void *stream);
+
+/* Mirror of the pybind `forward` signature (hip/fpemu_impl.cpp:27-37): mode string, size,
+ * scale, block_norm, block_size.  inplace <=> out == in.  block_norm with a usable block_size
+ * returns FPEMU_EUNSUPPORTED; like the reference (cpp:2020-2025) it is demoted to false when
+ * size % block_size != 0. */
+int fpemu_forward(const void *in, void *out, int dtype, const char *mode, uint64_t size,
+                  float scale, int block_norm, int block_size, uint64_t seed, uint64_t offset,
+                  void *stream);
+
+/* |x| max-reduction feeding the per-tensor scale (replaces torch.max(abs(flatten(t))),
+ * qutils.py:283, and the never-launched absmax0 kernel hip/fpemu_kernels.hip:194-220).
+ * *amax_bits = max(*amax_bits, max_i bits(|in[i]|)) as unsigned integers, which equals the
+ * float maximum and makes any NaN win (torch.max propagates NaN).  The caller zeroes
+ * *amax_bits (4 bytes, device) before the first call; several calls may accumulate into it. */
+int fpemu_amax(const void *in, uint64_t n, int dtype, uint32_t *amax_bits, void *stream);
+
+/* Cast with the scale derived ON DEVICE from an amax word (no host sync):
+ *   scale = fp32(fp32(1/vmax) * flt_max);  if (clamp && scale > 3.275e4) scale = 6.55e4
+ * exactly as quantize_tensor computes it (qutils.py:284-285; clamp=0 is the fine-grained
+ * branch qutils.py:328-330).  amax_bits is read, not modified. */
+int fpemu_cast_scaled(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
+                      const uint32_t *amax_bits, float flt_max, int clamp, uint64_t seed,
+                      uint64_t offset, uint64_t elem_base, void *stream);
+
+/* quantize_tensor's per-tensor "max" branch in one call (qutils.py:282-287): zero the
+ * workspace word, amax, device-side scale, cast.  amax_ws: 4 bytes of device memory owned by
+ * the caller (holds the amax bits afterwards). */
+int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
+                              float flt_max, uint32_t *amax_ws, uint64_t seed, uint64_t offset,
+                              void *stream);
+
+/* Launch-geometry override for benchmarking sweeps: blocks per launch cap (0 = default).
+ * Affects performance only, never results. */
+void fpemu_set_max_blocks(int max_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,133 @@
+"""ctypes loader for the CPU oracle (oracle/libfpemu_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module;
+nothing under fp8-emulation-toolkit_amd/ does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfpemu_oracle.so")
+
+FMT = {"E5M2": 0, "E4M3": 1, "E3M4": 2, "BF16": 3, "FP16": 4, "E5M2_DAZ": 5, "FP16_DAZ": 6}
+RMODE = {"RTZ": 0, "RNE": 1, "STOCHASTIC": 2, "RNAZ": 3, "RNTZ": 4, "RPINF": 5, "RNINF": 6}
+
+_lib = None
+
+
+def build():
+    """Compile the oracle (gcc, seconds).  Called by __graft_entry__.build()."""
+    subprocess.check_call(["make", "-C", _HERE, "libfpemu_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(_SO):
+        build()
+    L = ctypes.CDLL(_SO)
+    u64, u32, i32, f32 = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_float
+    vp = ctypes.c_void_p
+    L.orc_f32_to_f16_rne.restype = ctypes.c_uint16
+    L.orc_f32_to_f16_rne.argtypes = [f32]
+    L.orc_f16_to_f32.restype = f32
+    L.orc_f16_to_f32.argtypes = [ctypes.c_uint16]
+    L.orc_quantize_h.restype = ctypes.c_uint16
+    L.orc_quantize_h.argtypes = [ctypes.c_uint16, i32, i32, u32]
+    L.orc_cast_one.restype = f32
+    L.orc_cast_one.argtypes = [f32, i32, i32, f32, f32, u32]
+    L.orc_scale_reciprocal.restype = f32
+    L.orc_scale_reciprocal.argtypes = [f32]
+    L.orc_philox4x32_10.restype = None
+    L.orc_philox4x32_10.argtypes = [u32] * 6 + [vp]
+    L.orc_rand_bits.restype = u32
+    L.orc_rand_bits.argtypes = [u64, u64, u64, i32]
+    L.orc_cast_f32.restype = i32
+    L.orc_cast_f32.argtypes = [vp, vp, u64, i32, i32, f32, u64, u64, u64]
+    L.orc_cast_16.restype = i32
+    L.orc_cast_16.argtypes = [vp, vp, u64, i32, i32, i32, f32, u64, u64, u64]
+    L.orc_amax_f32.restype = f32
+    L.orc_amax_f32.argtypes = [vp, u64]
+    L.orc_scale_from_amax.restype = f32
+    L.orc_scale_from_amax.argtypes = [f32, f32]
+    L.orc_scale_from_amax_noclamp.restype = f32
+    L.orc_scale_from_amax_noclamp.argtypes = [f32, f32]
+    L.orc_build_lut.restype = None
+    L.orc_build_lut.argtypes = [i32, i32, vp]
+    L.orc_parse_mode.restype = i32
+    L.orc_parse_mode.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.orc_num_threads.restype = i32
+    L.orc_num_threads.argtypes = []
+    _lib = L
+    return L
+
+
+def parse_mode(mode):
+    f, r = ctypes.c_int(), ctypes.c_int()
+    if lib().orc_parse_mode(mode.encode(), ctypes.byref(f), ctypes.byref(r)) != 0:
+        raise ValueError("oracle: unknown mode %r" % (mode,))
+    return f.value, r.value
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def cast(x, mode, scale=1.0, seed=0, offset=0, elem_base=0, out=None):
+    """Oracle cast of a float32 numpy array (any shape) -> new float32 array."""
+    fmt, rmode = parse_mode(mode)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x) if out is None else out
+    rc = lib().orc_cast_f32(_ptr(x), _ptr(y), x.size, fmt, rmode, np.float32(scale), seed, offset,
+                            elem_base)
+    if rc != 0:
+        raise ValueError("oracle: invalid fmt/rmode for %r" % (mode,))
+    return y
+
+
+def cast16(x_bits, is_bf16, mode, scale=1.0, seed=0, offset=0, elem_base=0):
+    """Oracle cast of 16-bit storage given as a uint16 bit-pattern array."""
+    fmt, rmode = parse_mode(mode)
+    x = np.ascontiguousarray(x_bits, dtype=np.uint16)
+    y = np.empty_like(x)
+    rc = lib().orc_cast_16(_ptr(x), _ptr(y), x.size, int(bool(is_bf16)), fmt, rmode,
+                           np.float32(scale), seed, offset, elem_base)
+    if rc != 0:
+        raise ValueError("oracle: invalid fmt/rmode for %r" % (mode,))
+    return y
+
+
+def amax(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return np.float32(lib().orc_amax_f32(_ptr(x), x.size))
+
+
+def scale_from_amax(vmax, flt_max, clamp=True):
+    f = lib().orc_scale_from_amax if clamp else lib().orc_scale_from_amax_noclamp
+    return np.float32(f(np.float32(vmax), np.float32(flt_max)))
+
+
+def lut(mode):
+    fmt, rmode = parse_mode(mode)
+    t = np.empty(65536, dtype=np.uint16)
+    lib().orc_build_lut(fmt, rmode, _ptr(t))
+    return t
+
+
+def philox(key, ctr):
+    o = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(key[0], key[1], ctr[0], ctr[1], ctr[2], ctr[3], _ptr(o))
+    return o
+
+
+def rand_bits(seed, offset, idx, mode):
+    fmt, _ = parse_mode(mode)
+    return lib().orc_rand_bits(seed, offset, idx, fmt)
+
+
+def num_threads():
+    return lib().orc_num_threads()

@@ -1,0 +1,57 @@
+"""Shared helpers for the test-suite (test infrastructure)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+FLT_MAX = {"E5M2": 57344.0, "E4M3": 448.0, "E3M4": 30.0}
+
+DET_MODES = ["E5M2_RNE", "E4M3_RNE", "E3M4_RNE", "E5M2_RTZ", "E5M2_RNAZ", "E5M2_RNTZ", "E5M2_RPINF",
+             "E5M2_RNINF", "E5M2_DAZ_RNE", "E5M2_DAZ_RNAZ", "E5M2_DAZ_RNTZ", "BFLOAT16_RNE",
+             "FLOAT16_RNE", "FLOAT16_DAZ_RNE"]
+EXT_MODES = ["E4M3_RTZ", "E3M4_RTZ", "BFLOAT16_RTZ"]  # not defined by the reference: parity unpinned
+SR_MODES = ["E5M2_STOCHASTIC", "E4M3_STOCHASTIC", "E3M4_STOCHASTIC", "BFLOAT16_STOCHASTIC",
+            "FLOAT16_STOCHASTIC", "E5M2_DAZ_STOCHASTIC"]
+ALL_MODES = DET_MODES + EXT_MODES + SR_MODES
+
+
+def npz(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def jload(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def assert_bits_equal(got, want, what=""):
+    g, w = bits(got).ravel(), bits(want).ravel()
+    assert g.shape == w.shape, (what, g.shape, w.shape)
+    bad = np.nonzero(g != w)[0]
+    if bad.size:
+        i = bad[:8]
+        raise AssertionError("%s: %d / %d words differ; first at %s got %s want %s" % (
+            what, bad.size, g.size, i.tolist(), [hex(v) for v in g[i]], [hex(v) for v in w[i]]))
+
+
+def mixed_inputs(n, seed=1234):
+    """BASELINE config-2 style mix: 90 % log-normal magnitudes, 5 % exact zeros / format maxima /
+    ties, 5 % raw random bit patterns (NaN / Inf / denormals)."""
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(n) * np.exp(rng.standard_normal(n) * 4.0)).astype(np.float32)
+    k = n // 20
+    special = np.array([0.0, -0.0, 448.0, -448.0, 57344.0, -57344.0, 30.0, -30.0, 65504.0, 61440.0,
+                        1.0625, 1.125, 1.25, 0.001953125, 2.0 ** -10, 2.0 ** -16, 2.0 ** -17,
+                        1.5 * 2.0 ** -16, np.inf, -np.inf, 464.0, 480.0, 31.0, 30.5],
+                       dtype=np.float32)
+    idx = rng.choice(n, size=2 * k, replace=False)
+    x[idx[:k]] = special[rng.integers(0, special.size, size=k)]
+    raw = rng.integers(0, 2 ** 32, size=k, dtype=np.uint64).astype(np.uint32)
+    x.view(np.uint32)[idx[k:]] = raw
+    return x

@@ -1,0 +1,215 @@
+"""Generate the golden fixtures in tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference):
+
+    OMP_NUM_THREADS=1 python3 tests/golden/make_golden.py
+
+The reference's fpemu_cpp extension is compiled from its own sources by oracle/build_ref.py
+(native = AVX-512 routines, scalar = -mno-avx512f) and its Python package is imported from
+/root/reference.  Only data (inputs and the reference's outputs) is written here; no reference
+source text is stored.  SURVEY.md section 8(a) names which build is canonical per mode.
+
+Fixtures (all loadable with numpy.load(allow_pickle=False) / json):
+  luts.npz        every fp16 pattern (as fp32 input, scale 1) -> output bits, per deterministic mode
+  rawbits.npz     32 Ki raw random fp32 bit patterns + 32 Ki log-normal values -> output bits per mode
+  scaled.npz      4 Ki log-normal values x 5 scales x 4 modes
+  testpy64.json   the 64 edge-case inputs the reference's own pytquant/test.py holds x modes
+  sr_hist.json    scalar-reference stochastic-rounding round-up counts (distribution pin)
+  qtensor.npz     reference qutils.quantize_tensor (per-tensor / per-channel / fine-grained / mean)
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import build_ref  # noqa: E402
+
+torch.set_num_threads(1)  # the reference's scalar SR shares RNG state across OpenMP threads
+
+NAT = build_ref.load("native")
+SCA = build_ref.load("scalar")
+
+# mode -> build that is canonical for it; RNE of the FP8 formats agree on both.
+DET_MODES = {
+    "E5M2_RNE": NAT, "E4M3_RNE": NAT, "E3M4_RNE": NAT,
+    "E5M2_RTZ": SCA, "E5M2_RNAZ": SCA, "E5M2_RNTZ": SCA, "E5M2_RPINF": SCA, "E5M2_RNINF": SCA,
+    "E5M2_DAZ_RNE": SCA, "E5M2_DAZ_RNAZ": SCA, "E5M2_DAZ_RNTZ": SCA,
+    "BFLOAT16_RNE": NAT, "FLOAT16_RNE": SCA, "FLOAT16_DAZ_RNE": SCA,
+}
+
+
+def ref_cast(mod, x, mode, scale=1.0):
+    t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32).copy())
+    out = mod.forward(t, mode, t.numel(), False, float(scale), False, 1)[0]
+    return out.numpy().view(np.uint32).copy()
+
+
+def lognormal(rng, n):
+    return (rng.standard_normal(n) * np.exp(rng.standard_normal(n) * 4.0)).astype(np.float32)
+
+
+def gen_luts():
+    h = np.arange(65536, dtype=np.uint16)
+    x = h.view(np.float16).astype(np.float32)
+    out = {"input_bits": x.view(np.uint32)}
+    for mode, mod in DET_MODES.items():
+        if mode.startswith("BFLOAT16"):
+            continue
+        out[mode] = ref_cast(mod, x, mode)
+    np.savez_compressed(os.path.join(HERE, "luts.npz"), **out)
+
+
+def gen_rawbits():
+    rng = np.random.default_rng(20241220)
+    raw = rng.integers(0, 2 ** 32, size=32768, dtype=np.uint64).astype(np.uint32)
+    ln = lognormal(rng, 32768).view(np.uint32)
+    x = np.concatenate([raw, ln])
+    out = {"input_bits": x}
+    for mode, mod in DET_MODES.items():
+        out[mode] = ref_cast(mod, x.view(np.float32), mode)
+    np.savez_compressed(os.path.join(HERE, "rawbits.npz"), **out)
+
+
+SCALES = [0.37, 3.0, 116.894, 0.0078125, 6.55e4]
+
+
+def gen_scaled():
+    rng = np.random.default_rng(77)
+    x = lognormal(rng, 4096)
+    out = {"input_bits": x.view(np.uint32), "scales": np.array(SCALES, dtype=np.float32)}
+    for mode in ("E5M2_RNE", "E4M3_RNE", "E3M4_RNE", "E5M2_RTZ"):
+        for i, s in enumerate(SCALES):
+            out["%s/%d" % (mode, i)] = ref_cast(DET_MODES[mode], x, mode, np.float32(s))
+    np.savez_compressed(os.path.join(HERE, "scaled.npz"), **out)
+
+
+def gen_testpy64():
+    # The only reference-authored known-input set: the 64-value tensor literal in the
+    # reference's pytquant/test.py.  Values are parsed out of that file at generation time.
+    src = open("/root/reference/mpemu/pytquant/test.py").read()
+    vals = None
+    for body in re.findall(r"\ninput = torch\.tensor\(np\.array\(\[\[(.*?)\]\]\)", src, re.S):
+        v = [float(t) for t in re.findall(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?", body)]
+        if len(v) == 64:  # the active literal (the other one is the commented-out FP4 vector)
+            vals = v
+    assert vals is not None
+    x = np.array(vals, dtype=np.float32)
+    doc = {"input_bits": ["%08x" % v for v in x.view(np.uint32)], "modes": {}}
+    for mode, mod in DET_MODES.items():
+        # the reference's scalar routines handle a 64-element call's (size % 32 == 0) through the
+        # AVX-512 prefix on the native build; DET_MODES already maps each mode to its canonical build
+        doc["modes"][mode] = ["%08x" % v for v in ref_cast(mod, x, mode)]
+    with open(os.path.join(HERE, "testpy64.json"), "w") as f:
+        json.dump(doc, f, indent=0)
+
+
+def gen_sr_hist():
+    """Round-up counts of the scalar reference's stochastic modes.
+
+    For each format: N draws of a constant input whose dropped field has residue r; count how
+    many outputs equal the upper neighbour.  The scalar RNG is stateful and unseeded, so these are
+    statistical pins (binomial), not bit patterns."""
+    N = 1 << 16
+    doc = {"N": N, "cases": []}
+
+    def run(mode, xs, lo_hi):
+        for x, (lo, hi), p in zip(xs, lo_hi, [None] * len(xs)):
+            out = ref_cast(SCA, np.full(N, x, dtype=np.float32), mode).view(np.float32)
+            n_hi = int((out == np.float32(hi)).sum())
+            n_lo = int((out == np.float32(lo)).sum())
+            doc["cases"].append({"mode": mode, "x_bits": "%08x" % np.float32(x).view(np.uint32),
+                                 "lo_bits": "%08x" % np.float32(lo).view(np.uint32),
+                                 "hi_bits": "%08x" % np.float32(hi).view(np.uint32),
+                                 "n_lo": n_lo, "n_hi": n_hi})
+
+    # FP8 formats: x = fp16 pattern with exponent 0 (1.0 <= x < 2) and every residue of the
+    # dropped field at a fixed kept mantissa; k = 8 / 7 / 6 dropped bits.
+    for mode, k in (("E5M2_STOCHASTIC", 8), ("E4M3_STOCHASTIC", 7), ("E3M4_STOCHASTIC", 6)):
+        step = max(1, (1 << k) // 32)
+        rs = list(range(0, 1 << k, step))
+        base = 0x3C00 | (1 << k)  # kept mantissa LSB set
+        xs, lh = [], []
+        for r in rs:
+            h = np.array([base | r], dtype=np.uint16).view(np.float16).astype(np.float32)[0]
+            lo = np.array([base], dtype=np.uint16).view(np.float16).astype(np.float32)[0]
+            hi = np.array([base + (1 << k)], dtype=np.uint16).view(np.float16).astype(np.float32)[0]
+            xs.append(h)
+            lh.append((lo, hi))
+        run(mode, xs, lh)
+    # E4M3 / E3M4 pseudo-subnormal range (fp16-normal, so SR applies after the dshift clear)
+    run("E4M3_STOCHASTIC", [0.005], [(0.0048828125, 0.00537109375)])
+    # BF16: 16 dropped bits of the fp32 pattern
+    for r in (0x0000, 0x0001, 0x1000, 0x4000, 0x8000, 0xC000, 0xF000, 0xFFFF):
+        u = np.array([0x3F810000 | r], dtype=np.uint32)
+        x = u.view(np.float32)[0]
+        lo = np.array([0x3F810000], dtype=np.uint32).view(np.float32)[0]
+        hi = np.array([0x3F820000], dtype=np.uint32).view(np.float32)[0]
+        run("BFLOAT16_STOCHASTIC", [x], [(lo, hi)])
+    # FP16: 13 dropped bits of the fp32 pattern
+    for r in (0x0000, 0x0001, 0x0400, 0x1000, 0x1800, 0x1FFF):
+        u = np.array([0x3F802000 | r], dtype=np.uint32)
+        x = u.view(np.float32)[0]
+        lo = np.array([0x3F802000], dtype=np.uint32).view(np.float32)[0]
+        hi = np.array([0x3F804000], dtype=np.uint32).view(np.float32)[0]
+        run("FLOAT16_STOCHASTIC", [x], [(lo, hi)])
+    # the survey's spot values
+    run("E5M2_STOCHASTIC", [1.1], [(1.0, 1.25)])
+    run("E4M3_STOCHASTIC", [1.03], [(1.0, 1.125)])
+    run("E3M4_STOCHASTIC", [1.01], [(1.0, 1.0625)])
+    with open(os.path.join(HERE, "sr_hist.json"), "w") as f:
+        json.dump(doc, f, indent=0)
+
+
+def gen_qtensor():
+    """Reference qutils.quantize_tensor outputs (the Python caller of the cast, qutils.py:264-345)."""
+    # scalar build: the AVX-512 prefix of the native build silently runs RNE for E5M2_RTZ
+    # (SURVEY 8(a) row a2); every RNE case is identical on both builds.
+    build_ref.import_reference_package("scalar")
+    from mpemu import qutils
+
+    g = torch.Generator().manual_seed(5)
+    tensors = {
+        "randn": torch.randn(24, 40, generator=g),
+        "small": torch.randn(24, 40, generator=g) * 1e-3,
+        "large": torch.randn(24, 40, generator=g) * 300.0,
+        "tiny": torch.randn(24, 40, generator=g) * 1e-7,
+        "zeros": torch.zeros(8, 16),
+        "conv": torch.randn(6, 4, 3, 3, generator=g) * 0.2,
+        "odd": torch.randn(7, 13, generator=g) * 5.0,
+    }
+    cases = [
+        ("e4m3", "rne", "per-tensor", 1), ("e5m2", "rne", "per-tensor", 1),
+        ("e3m4", "rne", "per-tensor", 1), ("e4m3", "rne", "per-channel", 1),
+        ("e5m2", "rne", "per-channel", 1), ("e3m4", "rne", "per-channel", 1),
+        ("e4m3", "rne", "per-tensor-mean", 1), ("e4m3", "rne", "None", 1),
+        ("e5m2", "rtz", "None", 1), ("e4m3", "rne", "fine-grained", 8),
+        ("e3m4", "rne", "fine-grained", 4),
+    ]
+    out = {}
+    names = []
+    for tname, t in tensors.items():
+        out["in/" + tname] = t.numpy().view(np.uint32)
+        for dtype, scheme, scaling, gs in cases:
+            if scaling == "fine-grained" and (t.dim() < 2 or tname == "zeros"):
+                continue
+            cfg = qutils.TensorQuantConfig(dtype, scheme, scaling, gs)
+            for inplace in (False, True):
+                q = qutils.quantize_tensor(t.clone(), cfg, None, inplace=inplace)
+                key = "%s|%s|%s|%s|%d|%d" % (tname, dtype, scheme, scaling, gs, int(inplace))
+                out["out/" + key] = q.detach().numpy().view(np.uint32)
+                names.append(key)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "qtensor.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor"]
+    for w in which:
+        globals()["gen_" + w]()
+        print("golden:", w, "done")
