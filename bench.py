@@ -1,0 +1,213 @@
+"""bench.py -- throughput of the fpemu cast hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input: the out-of-place
+E4M3_RNE cast (scale 1.0) of a 1 GiB fp32 tensor (BASELINE.json configs[1]) resident in HBM.
+With N > 1 every rank casts its own 1 GiB shard of an N GiB tensor (weak scaling); unscaled
+casts shard with no collective.  Rank 0 prints ONE JSON line.
+
+Extra (untimed for `value`) sections in the same line: per-mode rates for every format x
+rounding mode, the per-tensor-scaled path (amax + all-reduce(max) over RCCL when N > 1 + cast),
+the `roofline` of the dominant kernel from HIP events, and `cpu_baseline`: the CPU oracle
+(port of the reference algorithm, OpenMP) timed on this box's host cores on the same data.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "fp8-emulation-toolkit_amd"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_ELEM = 8     # fp32 read + fp32 write, unscaled or given-scale cast
+
+
+def synth(n, device, seed):
+    """BASELINE config-2 mix, generated on device: 90 % log-normal magnitudes, 5 % exact
+    zeros / format maxima / ties, 5 % raw random bit patterns (NaN / Inf / denormals)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn(n, device=device, generator=g)
+    x.mul_(torch.exp(torch.randn(n, device=device, generator=g) * 4.0))
+    sel = torch.rand(n, device=device, generator=g)
+    special = torch.tensor([0.0, -0.0, 448.0, -448.0, 57344.0, -57344.0, 30.0, -30.0, 65504.0, 1.0625,
+                            1.125, 1.25, 2.0 ** -9, 2.0 ** -10, 2.0 ** -16, 464.0], device=device)
+    pick = torch.randint(0, special.numel(), (n,), device=device, generator=g)
+    x = torch.where(sel < 0.05, special[pick], x)
+    del pick
+    raw = torch.randint(-2 ** 31, 2 ** 31 - 1, (n,), device=device, generator=g, dtype=torch.int64)
+    x = torch.where(sel > 0.95, raw.to(torch.int32).view(torch.float32), x)
+    return x.contiguous()
+
+
+def time_launches(fn, steps):
+    """Average device time of one launch from HIP events recorded on the launch stream."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    per = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    return sum(per) / len(per), min(per)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--elems", type=int, default=1 << 28, help="fp32 elements per GPU (default 1 GiB)")
+    ap.add_argument("--mode", default="E4M3_RNE")
+    ap.add_argument("--no-extras", action="store_true", help="skip per-mode table and cpu baseline")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mpemu.pytquant.hip import _binding as hip
+
+    hip.lib()
+    n = args.elems
+    x = synth(n, dev, 1234 + rank)
+    y = torch.empty_like(x)
+    fmt, rm = hip.parse_mode(args.mode)
+
+    def step():
+        hip.cast_(x, y, fmt, rm, scale=1.0, seed=1, offset=0, elem_base=rank * n)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    ms = (t1 - t0) * 1e3 / args.steps
+    if world > 1:
+        t = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+    value = world * n / (ms * 1e-3)
+
+    # roofline of the dominant kernel: HIP events around each launch on the launch stream
+    avg_ms, min_ms = time_launches(step, max(10, min(args.steps, 50)))
+    achieved = BYTES_PER_ELEM * n / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.isfile(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "cast_kernel<E4M3,RNE,f32>", "avg_launch_ms": round(avg_ms, 5),
+                "min_launch_ms": round(min_ms, 5), "algorithmic_bytes_per_launch": BYTES_PER_ELEM * n}
+
+    extras = {}
+    cpu_baseline = None
+    if not args.no_extras:
+        # scaled path: amax (+ all-reduce(max) of one word over RCCL) + cast, 12 B/elem algorithmic
+        ws = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def scaled_step():
+            ws.zero_()
+            hip.amax_(x, ws)
+            if world > 1:
+                dist.all_reduce(ws, op=dist.ReduceOp.MAX)
+            hip.cast_scaled_(x, y, fmt, rm, ws, 448.0, clamp=True, seed=1, offset=0, elem_base=rank * n)
+
+        for _ in range(3):
+            scaled_step()
+        s_avg, _ = time_launches(scaled_step, 10)
+        extras["scaled_per_tensor"] = {"ms_per_step": round(s_avg, 5),
+                                       "GB/s_per_gpu": round(12 * n / (s_avg * 1e-3) / 1e9, 1),
+                                       "collective": "all_reduce(max) of 4 B" if world > 1 else "none"}
+
+        def inplace_step():
+            hip.cast_(y, y, fmt, rm, scale=1.0)
+
+        inplace_step()
+        i_avg, _ = time_launches(inplace_step, 10)
+        extras["inplace"] = {"ms": round(i_avg, 5), "GB/s": round(8 * n / (i_avg * 1e-3) / 1e9, 1)}
+
+        if rank == 0:
+            modes = {}
+            for m in ("E5M2_RNE", "E5M2_RTZ", "E5M2_STOCHASTIC", "E4M3_RNE", "E4M3_RTZ", "E4M3_STOCHASTIC",
+                      "E3M4_RNE", "E3M4_RTZ", "E3M4_STOCHASTIC", "BFLOAT16_RNE", "BFLOAT16_RTZ",
+                      "BFLOAT16_STOCHASTIC"):
+                f, r = hip.parse_mode(m)
+
+                def mstep(f=f, r=r):
+                    hip.cast_(x, y, f, r, scale=1.0, seed=1, offset=3)
+
+                mstep()
+                a, _ = time_launches(mstep, 10)
+                modes[m] = round(8 * n / (a * 1e-3) / 1e9, 1)
+            extras["modes_GB/s"] = modes
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        import numpy as np
+
+        import orc
+
+        sample = min(n, 1 << 28)
+        hx = x[:sample].cpu().numpy()
+        orc.cast(hx[: 1 << 24], args.mode)  # warm pass (threads, page tables)
+        out = np.empty_like(hx)
+        out.fill(0)
+        c0 = time.perf_counter()
+        orc.cast(hx, args.mode, out=out)
+        c1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        chk = slice(0, 1 << 22)
+        same = bool(np.array_equal(y[chk].cpu().numpy().view(np.uint32), out[chk].view(np.uint32)))
+        cpu_baseline = {"value": round(sample / (c1 - c0), 1), "unit": "elements/s",
+                        "cores": orc.num_threads(), "kind": "port",
+                        "sample": "%s over the first %d elements of the same tensor, one timed pass of the "
+                                  "OpenMP C oracle (oracle/fpemu_oracle.c), output pre-faulted" % (args.mode, sample),
+                        "gpu_matches_oracle_on_first_4Mi": same}
+
+    if rank == 0:
+        line = {
+            "metric": "quantized elements/sec, %s fpemu cast of a 1 GiB fp32 tensor per GPU" % args.mode,
+            "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %s out-of-place cast, %d fp32 elements (%.2f GiB) "
+                                   "per GPU, scale 1.0, inputs resident in HBM" % (args.mode, n, n * 4 / 2 ** 30),
+                       "sharding": "dp%d: contiguous shards, no collective on the unscaled path" % world},
+            "hbm_GB/s_per_gpu": round(BYTES_PER_ELEM * n / (ms * 1e-3) / 1e9, 1),
+            "hbm_frac_of_peak": round(BYTES_PER_ELEM * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -159,7 +159,11 @@ __device__ __forceinline__ float cast_one(float x, float scale, float rcp, uint3
     // contract (cpp:718-720); without this hipcc folds mul+cvt into v_fma_mixlo_f16.
     asm volatile("" : "+v"(p));
     const uint32_t q = quant_h<FMT, RM>(f32_to_h(p), rnd);
-    return h_to_f32(q) * rcp;
+    float r = h_to_f32(q) * rcp;
+    // Same on the way out: with 16-bit storage hipcc would fold cvt+mul+cvt into
+    // v_fma_mixlo_f16 d, rcp, q, 0 whose +0 addend turns a -0 product into +0.
+    asm volatile("" : "+v"(r));
+    return r;
   }
 }
 

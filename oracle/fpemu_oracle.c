@@ -60,7 +60,10 @@ float orc_f16_to_f32(uint16_t h) {
   uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
   uint32_t e = (h >> 10) & 0x1Fu;
   uint32_t m = h & 0x03FFu;
-  if (e == 0x1Fu) return u2f(sign | 0x7F800000u | (m << 13));
+  if (e == 0x1Fu) { /* a conversion instruction quiets a signalling NaN (vcvtph2ps, v_cvt_f32_f16) */
+    if (m) m |= 0x0200u;
+    return u2f(sign | 0x7F800000u | (m << 13));
+  }
   if (e != 0) return u2f(sign | ((e + 112u) << 23) | (m << 13));
   if (m == 0) return u2f(sign);
   /* subnormal: normalise */

@@ -1,0 +1,69 @@
+"""The C-ABI library loads and exports every symbol include/fpemu_hip.h declares; the mode
+table agrees with the oracle's.  No compute calls (CPU only)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import orc
+from _util import ALL_MODES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "fpemu_hip.h")
+SO = os.path.join(ROOT, "fp8-emulation-toolkit_amd", "mpemu", "pytquant", "hip", "libfpemu_hip.so")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fpemu_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 9, names
+    L = ctypes.CDLL(SO)
+    for n in names:
+        assert hasattr(L, n), "libfpemu_hip.so does not export " + n
+
+
+def test_header_cites_reference_for_each_entry_point():
+    src = open(HEADER).read()
+    for token in ("hip/fpemu_impl.cpp:27-53", "cpp/fpemu_impl.cpp:1878-2000", "qutils.py:283",
+                  "qutils.py:284-285"):
+        assert token in src, token
+
+
+def test_mode_table_matches_oracle():
+    from mpemu.pytquant.hip import _binding as b
+
+    for m in ALL_MODES:
+        assert b.parse_mode(m) == orc.parse_mode(m), m
+    with pytest.raises(ValueError):
+        b.parse_mode("E4M3_FOO")
+    with pytest.raises(ValueError):
+        b.parse_mode("")
+    for m in ("E4M3_IEEE_RNE", "E4M3_IEEE_STOCHASTIC", "FP4_NEAREST"):
+        with pytest.raises(NotImplementedError):
+            b.parse_mode(m)
+
+
+def test_argument_errors_without_gpu():
+    """Argument validation happens before any HIP call, so it is testable on a CPU-only box."""
+    from mpemu.pytquant.hip import _binding as b
+
+    L = b.lib()
+    assert L.fpemu_cast(None, None, 16, 0, 1, 1, 1.0, 0, 0, 0, None) == -1       # null buffers
+    assert b"null" in L.fpemu_last_error()
+    assert L.fpemu_cast(16, 16, 16, 7, 1, 1, 1.0, 0, 0, 0, None) == -1           # bad dtype
+    assert L.fpemu_cast(16, 16, 16, 0, 1, 5, 1.0, 0, 0, 0, None) == -1           # E4M3_RPINF undefined
+    assert L.fpemu_cast(18, 18, 16, 0, 1, 1, 1.0, 0, 0, 0, None) == -4           # misaligned fp32
+    assert L.fpemu_cast(16, 16, 16, 0, 1, 1, float("inf"), 0, 0, 0, None) == -1  # cpp:772-776
+    assert L.fpemu_cast(16, 16, 0, 0, 1, 1, 1.0, 0, 0, 0, None) == 0             # empty: no launch
+    assert L.fpemu_forward(16, 16, 0, b"NOPE", 16, 1.0, 0, 1, 0, 0, None) == -2
+    assert L.fpemu_forward(16, 16, 0, b"E4M3_RNE", 16, 1.0, 1, 4, 0, 0, None) == -3  # block_norm
+    assert L.fpemu_amax(None, 4, 0, None, None) == -1
+    assert L.fpemu_amax(16, 0, 0, 16, None) == 0
+    assert L.fpemu_cast_scaled(16, 16, 4, 0, 1, 1, None, 448.0, 1, 0, 0, 0, None) == -1
+    assert L.fpemu_quantize_per_tensor(16, 16, 4, 0, 1, 1, 448.0, None, 0, 0, None) == -1
