@@ -8,11 +8,15 @@
 //   fpemu_common_function           mpemu/pytquant/cpp/fpemu_impl.cpp:1866-2009
 // (one element per thread, 4-byte accesses, hipDeviceSynchronize per call, racy global RNG).
 //
-// Memory layout: buffers are flat and contiguous.  A wavefront iteration covers one
-// "superblock" = 4 slots x 64 lanes x 16 B = 4 KiB; lane L of the wave touches the four
-// 16-byte vectors {slot*64 + L}.  Every load/store instruction of a wave is therefore one
-// fully coalesced 1 KiB segment.  Elements past the last whole superblock (and whole buffers
-// whose pointers are not 16-byte aligned) go through a 4-byte-per-lane path in the same launch.
+// Memory layout: buffers are flat and contiguous.  A wavefront covers one "superblock" =
+// U slots x 64 lanes x 16 B; lane L of the wave touches the U 16-byte vectors {slot*64 + L}, so
+// every load/store instruction of a wave is one fully coalesced 1 KiB segment.  Deterministic
+// modes use U = 1 (one vector per lane, one superblock per wave, no loop: the grid IS the
+// tensor -- measured fastest on MI355X, tools/sweep.hip); stochastic modes use U = 4 so that one
+// Philox4x32 call per lane (16 random bytes) feeds its 16 elements.  Loads are non-temporal
+// (read once); stores carry "sc1 nt" (streaming write-through): +2 % over nt stores, measured.
+// Elements past the last whole superblock (and whole buffers whose pointers are not 16-byte
+// aligned) go through a 4-byte-per-lane path in the same launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -29,7 +33,8 @@ namespace {
 
 constexpr int kBlock = 256;         // 4 wavefronts
 constexpr int kWavesPerBlock = 4;
-constexpr int kDefaultMaxBlocks = 256 * 8;  // 256 CUs x 8 resident 256-thread blocks
+constexpr int kDefaultMaxBlocks = 0x7FFFFFFF;  // cast: one superblock per wave, no loop
+constexpr int kAmaxMaxBlocks = 256 * 16;       // amax: looped, one atomic per block
 
 int g_max_blocks = 0;
 thread_local char g_err[256] = "";
@@ -61,6 +66,15 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
   return ((u & 0x7FFFFFFFu) > 0x7F800000u) ? nan : rn;
 }
 
+// Streaming 16-byte store with the "sc1 nt" policy bits (write-through, non-temporal): measured
+// +2 % over a plain nt store on MI355X for this read-once / write-once stream (tools/sweep.hip);
+// the builtin only offers "nt".  Vector store only; nothing in the launch reads it back.
+// The trailing s_nop 1 is required: hipcc pads no hazards inside an asm statement, and a VALU
+// write to the data registers right after a >64-bit store would overtake the store's read of them.
+__device__ __forceinline__ void store_stream(u32x4 *p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 template <int DT> __device__ __forceinline__ float load_elem16(uint32_t b) {
   if constexpr (DT == FPEMU_F16) return h_to_f32(b);
   else return u2f(b << 16);
@@ -79,11 +93,14 @@ __device__ __forceinline__ uint32_t lane_noise(const Philox4 (&p)[NCALLS], unsig
   return w;  // consumers mask the bits they use
 }
 
+template <int RM> constexpr int slots_per_wave() { return RM == STOCHASTIC ? 4 : 1; }
+
 template <int FMT, int RM, int DT>
 __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out_,
                                                       uint64_t nsb, uint64_t n, CastParams prm) {
   constexpr unsigned V = Storage<DT>::V;
-  constexpr uint64_t SB_ELEMS = (uint64_t)V * 64u * 4u;
+  constexpr int U = slots_per_wave<RM>();
+  constexpr uint64_t SB_ELEMS = (uint64_t)V * 64u * U;
   constexpr bool SR = (RM == STOCHASTIC);
   constexpr int NCALLS = SR ? (int)(4u * V * noise_bytes<FMT>() / 16u) : 1;
 
@@ -101,10 +118,10 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out
   const uint64_t sb_base = prm.elem_base / SB_ELEMS;
 
   for (uint64_t sb = wave; sb < nsb; sb += nwaves) {
-    const uint64_t v0 = sb * 256u + lane;
-    u32x4 v[4];
+    const uint64_t v0 = sb * (64u * U) + lane;
+    u32x4 v[U];
 #pragma unroll
-    for (int s = 0; s < 4; s++) v[s] = __builtin_nontemporal_load(&in[v0 + (uint64_t)s * 64u]);
+    for (int s = 0; s < U; s++) v[s] = __builtin_nontemporal_load(&in[v0 + (uint64_t)s * 64u]);
 
     Philox4 p[NCALLS];
     if constexpr (SR) {
@@ -114,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out
     }
 
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < U; s++) {
       u32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out
           o[j] = (store_elem16<DT>(y0) & 0xFFFFu) | (store_elem16<DT>(y1) << 16);
         }
       }
-      __builtin_nontemporal_store(o, &out[v0 + (uint64_t)s * 64u]);
+      store_stream(&out[v0 + (uint64_t)s * 64u], o);
     }
   }
 
@@ -175,30 +192,37 @@ template <int DT> __device__ __forceinline__ uint32_t absmax_word(uint32_t m, ui
   }
 }
 
+constexpr int kAmaxVPT = 8;  // 16-byte vectors in flight per lane
+
 template <int DT>
 __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ in_, uint64_t nvec,
                                                       uint64_t n, uint32_t *amax_bits) {
   constexpr unsigned V = Storage<DT>::V;
+  constexpr int U = kAmaxVPT;
   const u32x4 *in = reinterpret_cast<const u32x4 *>(in_);
-  const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const unsigned lane = threadIdx.x & 63u;
+  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  const uint64_t nsb = nvec / (64u * U);
   uint32_t m = 0u;
-  uint64_t i = tid;
-  for (; i + 3u * stride < nvec; i += 4u * stride) {
-    u32x4 v[4];
+  for (uint64_t sb = wave; sb < nsb; sb += nwaves) {  // one trip for every grid launch_amax picks
+    const uint64_t v0 = sb * (64u * U) + lane;
+    u32x4 v[U];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(&in[i + (uint64_t)k * stride]);
+    for (int k = 0; k < U; k++) v[k] = __builtin_nontemporal_load(&in[v0 + (uint64_t)k * 64u]);
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < U; k++)
 #pragma unroll
       for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, v[k][j]);
   }
-  for (; i < nvec; i += stride) {
+  // leftover vectors, then leftover elements / unaligned buffers (nvec == 0)
+  const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = nsb * (64u * U) + tid; i < nvec; i += stride) {
     const u32x4 v = __builtin_nontemporal_load(&in[i]);
 #pragma unroll
     for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, v[j]);
   }
-  // element tail / unaligned buffers (nvec == 0)
   using elem_t = typename Storage<DT>::elem;
   const elem_t *ein = reinterpret_cast<const elem_t *>(in_);
   for (uint64_t e = nvec * V + tid; e < n; e += stride) {
@@ -208,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
 
   m = wave_max_u32(m);
   __shared__ uint32_t part[kWavesPerBlock];
-  if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = m;
+  if (lane == 0u) part[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t r = part[0];
@@ -217,7 +241,11 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
     // storage pattern -> fp32 pattern (order preserving; NaN stays above +Inf)
     if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
     else if constexpr (DT == FPEMU_BF16) r = r << 16;
-    if (r != 0u) __hip_atomic_fetch_max(amax_bits, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The running maximum only grows, so a block whose maximum does not beat the value already
+    // published can skip its atomic: after the first wave of blocks almost all do, which keeps
+    // tens of thousands of blocks off the single word.  (A stale read only costs a redundant atomic.)
+    const uint32_t seen = __hip_atomic_load(amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (r > seen) __hip_atomic_fetch_max(amax_bits, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -267,8 +295,10 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
   if (((uintptr_t)in % es) || ((uintptr_t)out % es))
     return fail(FPEMU_EALIGN, "fpemu_cast: buffer not aligned to its element size");
 
-  const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 256u;
-  const bool vec_ok = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (prm.elem_base % sb_elems) == 0;
+  // stochastic: 4 slots per wave (the noise layout's superblock); deterministic: 1
+  const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 64u * (rmode == STOCHASTIC ? 4u : 1u);
+  const bool vec_ok = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 &&
+                      (rmode != STOCHASTIC || (prm.elem_base % sb_elems) == 0);
   const uint64_t nsb = vec_ok ? n / sb_elems : 0;
   const uint64_t tail = n - nsb * sb_elems;
   uint64_t blocks = (nsb + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -370,11 +400,14 @@ int fpemu_amax(const void *in, uint64_t n, int dtype, uint32_t *amax_bits, void 
   if ((uintptr_t)in % elem_size(dtype)) return fail(FPEMU_EALIGN, "fpemu_amax: buffer not aligned");
   const bool vec_ok = ((uintptr_t)in % 16u) == 0;
   const uint64_t nvec = vec_ok ? n / vec_elems(dtype) : 0;
-  const uint64_t work = nvec ? nvec : n;
-  uint64_t blocks = (work + kBlock - 1) / kBlock;
-  // each thread should see >= 4 vectors before paying for the block reduction
-  if (nvec) blocks = (blocks + 3) / 4;
-  if (blocks > (uint64_t)max_blocks()) blocks = (uint64_t)max_blocks();
+  // one superblock (kAmaxVPT x 64 vectors) per wave; unaligned buffers: one element per lane-step
+  const uint64_t nsb = nvec / (64u * kAmaxVPT);
+  uint64_t blocks = (nsb + kWavesPerBlock - 1) / kWavesPerBlock;
+  const uint64_t rest = n - nsb * 64u * kAmaxVPT * vec_elems(dtype);
+  uint64_t rest_blocks = (rest + kBlock - 1) / kBlock;
+  if (rest_blocks > (uint64_t)kAmaxMaxBlocks) rest_blocks = (uint64_t)kAmaxMaxBlocks;
+  if (blocks < rest_blocks) blocks = rest_blocks;
+  if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
   if (blocks == 0) blocks = 1;
   void (*fn)(const void *, uint64_t, uint64_t, uint32_t *) =
       dtype == FPEMU_F32 ? amax_kernel<FPEMU_F32>

@@ -1,0 +1,315 @@
+// tools/sweep.hip -- launch-geometry / cache-policy sweep for the streaming cast (tuning aid,
+// not part of the product).  Every variant runs the real E4M3_RNE arithmetic of
+// fpemu_device.hpp; variants differ only in how bytes move.  Interleaved rounds in ONE process
+// (cdna_hip_programming.md rule 24); prints median and min GB/s per variant.
+//
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o tools/sweep tools/sweep.hip
+//   ./tools/sweep [elements=268435456] [rounds=15]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../fp8-emulation-toolkit_amd/csrc/fpemu_device.hpp"
+#include "../include/fpemu_hip.h"
+
+using namespace fpemu;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <bool NT> __device__ __forceinline__ u32x4 ld(const u32x4 *p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+template <bool NT> __device__ __forceinline__ void st(u32x4 *p, u32x4 v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+template <bool COMPUTE> __device__ __forceinline__ u32x4 work(u32x4 v, float scale, float rcp) {
+  if constexpr (!COMPUTE) return v;
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; j++) o[j] = f2u(cast_one<E4M3, RNE>(u2f(v[j]), scale, rcp, 0u));
+  return o;
+}
+
+// Variant A: wave-strided superblocks of U slots (U x 1 KiB per wave iteration), grid-stride.
+template <int BLOCK, int U, bool NTL, bool NTS, bool COMPUTE>
+__global__ __launch_bounds__(BLOCK) void k_wave(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
+  constexpr int WPB = BLOCK / 64;
+  const unsigned lane = threadIdx.x & 63u;
+  const uint64_t wave = (uint64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
+  const uint64_t nsb = nvec / (64u * U);
+  for (uint64_t sb = wave; sb < nsb; sb += nwaves) {
+    const uint64_t v0 = sb * (64u * U) + lane;
+    u32x4 v[U];
+#pragma unroll
+    for (int s = 0; s < U; s++) v[s] = ld<NTL>(&in[v0 + (uint64_t)s * 64u]);
+#pragma unroll
+    for (int s = 0; s < U; s++) st<NTS>(&out[v0 + (uint64_t)s * 64u], work<COMPUTE>(v[s], scale, rcp));
+  }
+}
+
+// Variant B: thread-strided (classic grid-stride over vectors, U loads in flight, stride = grid).
+template <int BLOCK, int U, bool NTL, bool NTS, bool COMPUTE>
+__global__ __launch_bounds__(BLOCK) void k_grid(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
+  const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+  uint64_t i = tid;
+  for (; i + (U - 1) * stride < nvec; i += U * stride) {
+    u32x4 v[U];
+#pragma unroll
+    for (int s = 0; s < U; s++) v[s] = ld<NTL>(&in[i + (uint64_t)s * stride]);
+#pragma unroll
+    for (int s = 0; s < U; s++) st<NTS>(&out[i + (uint64_t)s * stride], work<COMPUTE>(v[s], scale, rcp));
+  }
+  for (; i < nvec; i += stride) st<NTS>(&out[i], work<COMPUTE>(ld<NTL>(&in[i]), scale, rcp));
+}
+
+// Variant C: block-contiguous chunks: block b owns chunk [b*C, (b+1)*C) of the buffer (C = nvec/grid),
+// walks it with BLOCK-wide rows, U rows in flight.  Each CU streams one long contiguous range.
+template <int BLOCK, int U, bool NTL, bool NTS, bool COMPUTE>
+__global__ __launch_bounds__(BLOCK) void k_chunk(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
+  const uint64_t per = (nvec + gridDim.x - 1) / gridDim.x;
+  const uint64_t beg = (uint64_t)blockIdx.x * per;
+  uint64_t end = beg + per;
+  if (end > nvec) end = nvec;
+  uint64_t i = beg + threadIdx.x;
+  for (; i + (uint64_t)(U - 1) * BLOCK < end; i += (uint64_t)U * BLOCK) {
+    u32x4 v[U];
+#pragma unroll
+    for (int s = 0; s < U; s++) v[s] = ld<NTL>(&in[i + (uint64_t)s * BLOCK]);
+#pragma unroll
+    for (int s = 0; s < U; s++) st<NTS>(&out[i + (uint64_t)s * BLOCK], work<COMPUTE>(v[s], scale, rcp));
+  }
+  for (; i < end; i += BLOCK) st<NTS>(&out[i], work<COMPUTE>(ld<NTL>(&in[i]), scale, rcp));
+}
+
+
+// Variant D: no loop, block -> chunk permutation: concurrently dispatched blocks (consecutive ids)
+// are spread over R distant regions: chunk = (b % R) * (G / R) + b / R.  R = 8 makes every XCD
+// (blocks b, b+8, ... share one) stream its own contiguous eighth of the buffer.
+template <int BLOCK, int U, int R, bool COMPUTE>
+__global__ __launch_bounds__(BLOCK) void k_perm(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
+  constexpr int WPB = BLOCK / 64;
+  const unsigned lane = threadIdx.x & 63u;
+  const uint64_t G = gridDim.x;
+  const uint64_t b = blockIdx.x;
+  const uint64_t chunk = (b % R) * (G / R) + b / R;
+  const uint64_t sb = chunk * WPB + (threadIdx.x >> 6);
+  const uint64_t v0 = sb * (64u * U) + lane;
+  if (v0 + (U - 1) * 64u >= nvec) return;
+  u32x4 v[U];
+#pragma unroll
+  for (int s = 0; s < U; s++) v[s] = __builtin_nontemporal_load(&in[v0 + (uint64_t)s * 64u]);
+#pragma unroll
+  for (int s = 0; s < U; s++) __builtin_nontemporal_store(work<COMPUTE>(v[s], scale, rcp), &out[v0 + (uint64_t)s * 64u]);
+}
+
+
+// Variant E: one vector per lane, no loop, cache-policy bits chosen by inline asm.
+// LP / SP index into the modifier tables below.
+#define LD_ASM(mods) asm volatile("global_load_dwordx4 %0, %1, off " mods "\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory")
+#define ST_ASM(mods) asm volatile("global_store_dwordx4 %0, %1, off " mods : : "v"(dst), "v"(o) : "memory")
+template <int LP, int SP, bool COMPUTE>
+__global__ __launch_bounds__(256) void k_pol(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= nvec) return;
+  const u32x4 *src = in + i;
+  u32x4 *dst = out + i;
+  u32x4 v;
+  if constexpr (LP == 0) LD_ASM("");
+  else if constexpr (LP == 1) LD_ASM("nt");
+  else if constexpr (LP == 2) LD_ASM("sc1");
+  else if constexpr (LP == 3) LD_ASM("sc0 sc1");
+  else if constexpr (LP == 4) LD_ASM("sc1 nt");
+  else if constexpr (LP == 5) LD_ASM("sc0 sc1 nt");
+  else LD_ASM("sc0");
+  u32x4 o = work<COMPUTE>(v, scale, rcp);
+  if constexpr (SP == 0) ST_ASM("");
+  else if constexpr (SP == 1) ST_ASM("nt");
+  else if constexpr (SP == 2) ST_ASM("sc1");
+  else if constexpr (SP == 3) ST_ASM("sc0 sc1");
+  else if constexpr (SP == 4) ST_ASM("sc1 nt");
+  else if constexpr (SP == 5) ST_ASM("sc0 sc1 nt");
+  else ST_ASM("sc0");
+}
+
+// Variant F: one lane handles vector i and vector i + nvec/2 (two distant regions in flight).
+template <bool COMPUTE>
+__global__ __launch_bounds__(256) void k_two(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  const uint64_t h = nvec / 2;
+  if (i >= h) return;
+  u32x4 a = __builtin_nontemporal_load(&in[i]);
+  u32x4 b = __builtin_nontemporal_load(&in[i + h]);
+  __builtin_nontemporal_store(work<COMPUTE>(a, scale, rcp), &out[i]);
+  __builtin_nontemporal_store(work<COMPUTE>(b, scale, rcp), &out[i + h]);
+}
+
+
+// Reference streams: read-only (xor-reduce, one store per wave) and write-only.
+template <bool NT>
+__global__ __launch_bounds__(256) void k_read(const u32x4 *in, u32x4 *out, uint64_t nvec, float, float) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= nvec) return;
+  u32x4 v = ld<NT>(&in[i]);
+  uint32_t x = v[0] ^ v[1] ^ v[2] ^ v[3];
+  if (x == 0x12345678u) out[i] = v;  // practically never taken; keeps the load alive
+}
+template <int SP>
+__global__ __launch_bounds__(256) void k_write(const u32x4 *in, u32x4 *out, uint64_t nvec, float, float) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= nvec) return;
+  u32x4 o = {(uint32_t)i, 1u, 2u, 3u};
+  u32x4 *dst = out + i;
+  if constexpr (SP == 0) ST_ASM("");
+  else if constexpr (SP == 1) ST_ASM("nt");
+  else ST_ASM("sc1 nt");
+}
+
+
+// amax variants: VPT vectors per lane, no loop, block reduce, conditional atomic.
+template <int BLOCK, int VPT, bool COND>
+__global__ __launch_bounds__(BLOCK) void k_amax(const u32x4 *in, u32x4 *out, uint64_t nvec, float, float) {
+  constexpr int WPB = BLOCK / 64;
+  const unsigned lane = threadIdx.x & 63u;
+  const uint64_t wave = (uint64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+  const uint64_t v0 = wave * (64u * VPT) + lane;
+  uint32_t m = 0;
+  if (v0 + (VPT - 1) * 64u < nvec) {
+    u32x4 v[VPT];
+#pragma unroll
+    for (int k = 0; k < VPT; k++) v[k] = __builtin_nontemporal_load(&in[v0 + (uint64_t)k * 64u]);
+#pragma unroll
+    for (int k = 0; k < VPT; k++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { uint32_t a = v[k][j] & 0x7FFFFFFFu; m = m > a ? m : a; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64); m = m > o ? m : o; }
+  __shared__ uint32_t part[WPB];
+  if (lane == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t r = part[0];
+    for (int w = 1; w < WPB; w++) r = r > part[w] ? r : part[w];
+    uint32_t *word = reinterpret_cast<uint32_t *>(out);
+    if (COND) {
+      uint32_t seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (r > seen) __hip_atomic_fetch_max(word, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_fetch_max(word, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+struct Variant {
+  std::string name;
+  void (*fn)(const u32x4 *, u32x4 *, uint64_t, float, float);
+  int block;
+  int grid;  // 0 = one wave-iteration per wave (no loop), else fixed
+  int vec_per_block_iter;
+  std::vector<float> ms;
+};
+
+constexpr int REPS = 4;
+
+int main(int argc, char **argv) {
+  const uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 10) : (1ull << 28);
+  const int rounds = argc > 2 ? atoi(argv[2]) : 9;
+  const uint64_t nvec = n / 4;
+  u32x4 *in, *out;
+  CK(hipMalloc(&in, n * 4));
+  CK(hipMalloc(&out, n * 4));
+  // random finite-ish data: xorshift on host for 64 Mi then tile
+  {
+    std::vector<uint32_t> h(1 << 24);
+    uint32_t s = 12345u;
+    for (auto &w : h) {
+      s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+      // float in roughly [-512, 512] with varied exponents
+      uint32_t e = 100u + (s >> 8) % 36u;
+      w = (s & 0x807FFFFFu) | (e << 23);
+    }
+    for (uint64_t off = 0; off < n; off += h.size())
+      CK(hipMemcpy((char *)in + off * 4, h.data(), std::min<uint64_t>(h.size(), n - off) * 4, hipMemcpyHostToDevice));
+  }
+  std::vector<Variant> vs;
+  auto add = [&](const char *nm, auto fn, int block, int grid, int vpi) { vs.push_back({nm, fn, block, grid, vpi, {}}); };
+  const int CU = 256;
+  // grid = 0 means "one iteration per wave": grid = nvec / (64*U*waves_per_block)
+  auto noloop = [&](int block, int U) { return (int)(nvec / (64ull * U * (block / 64))); };
+  const int g1 = noloop(256, 1);
+  add("READ-only nt U1 (x2 scale)", k_read<true>, 256, g1, 0);
+  add("amax B256 VPT1 cond", k_amax<256, 1, true>, 256, noloop(256, 1), 0);
+  add("amax B256 VPT2 cond", k_amax<256, 2, true>, 256, noloop(256, 2), 0);
+  add("amax B256 VPT4 cond", k_amax<256, 4, true>, 256, noloop(256, 4), 0);
+  add("amax B256 VPT8 cond", k_amax<256, 8, true>, 256, noloop(256, 8), 0);
+  add("amax B256 VPT16 cond", k_amax<256, 16, true>, 256, noloop(256, 16), 0);
+  add("amax B512 VPT4 cond", k_amax<512, 4, true>, 512, noloop(512, 4), 0);
+  add("amax B1024 VPT2 cond", k_amax<1024, 2, true>, 1024, noloop(1024, 2), 0);
+  add("amax B1024 VPT4 cond", k_amax<1024, 4, true>, 1024, noloop(1024, 4), 0);
+  add("amax B64 VPT4 cond", k_amax<64, 4, true>, 64, noloop(64, 4), 0);
+  add("amax B256 VPT4 always-atomic", k_amax<256, 4, false>, 256, noloop(256, 4), 0);
+  add("amax B256 VPT8 always-atomic", k_amax<256, 8, false>, 256, noloop(256, 8), 0);
+
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  std::vector<float> memcpy_ms, lib_ms, lib_inplace_ms, lib_sr_ms;
+  auto time_lib = [&](std::vector<float> &acc, int r, void *o, int rmode) {
+    int rc = fpemu_cast(in, o, n, FPEMU_F32, FPEMU_FMT_E4M3, rmode, 1.0f, 1, 0, 0, nullptr);
+    if (rc != 0) { printf("fpemu_cast rc=%d %s\n", rc, fpemu_last_error()); exit(1); }
+    CK(hipEventRecord(e0, 0));
+    for (int k = 0; k < REPS; k++) fpemu_cast(in, o, n, FPEMU_F32, FPEMU_FMT_E4M3, rmode, 1.0f, 1, 0, 0, nullptr);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 2) acc.push_back(ms / REPS);
+  };
+  for (int r = 0; r < rounds + 2; r++) {
+    for (auto &v : vs) {
+      // steady state: one untimed launch of the SAME variant first (the previous variant may have
+      // left dirty lines in L2 / Infinity Cache that this one would pay for, or a clean cache that
+      // absorbs this one's stores for free), then REPS back-to-back timed launches.
+      CK(hipMemsetAsync(out, 0, 64, 0));
+      hipLaunchKernelGGL(v.fn, dim3(v.grid), dim3(v.block), 0, 0, in, out, nvec, 1.0f, 1.0f);
+      CK(hipEventRecord(e0, 0));
+      for (int k = 0; k < REPS; k++)
+        hipLaunchKernelGGL(v.fn, dim3(v.grid), dim3(v.block), 0, 0, in, out, nvec, 1.0f, 1.0f);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r >= 2) v.ms.push_back(ms / REPS);
+    }
+    time_lib(lib_ms, r, out, FPEMU_RNE);
+    time_lib(lib_sr_ms, r, out, FPEMU_STOCHASTIC);
+    CK(hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, 0));
+    CK(hipEventRecord(e0, 0));
+    for (int k = 0; k < REPS; k++) CK(hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, 0));
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 2) memcpy_ms.push_back(ms / REPS);
+  }
+  auto report = [&](const std::string &nm, std::vector<float> ms) {
+    std::sort(ms.begin(), ms.end());
+    const double gb = 8.0 * n / 1e9;
+    printf("%-40s median %8.4f ms %8.1f GB/s   best %8.4f ms %8.1f GB/s\n", nm.c_str(), ms[ms.size() / 2],
+           gb / (ms[ms.size() / 2] * 1e-3), ms[0], gb / (ms[0] * 1e-3));
+  };
+  printf("n = %llu fp32 elements (%.2f GiB in + out %.2f GiB), %d rounds\n", (unsigned long long)n, n * 4.0 / (1 << 30),
+         n * 4.0 / (1 << 30), rounds);
+  for (auto &v : vs) report(v.name, v.ms);
+  report("LIB fpemu_cast E4M3_RNE out-of-place", lib_ms);
+  report("LIB fpemu_cast E4M3_STOCHASTIC", lib_sr_ms);
+  report("hipMemcpyAsync D2D", memcpy_ms);
+  return 0;
+}
