@@ -7,3 +7,4 @@ include/fpemu_hip.h); see DESIGN.md.
 """
 from . import pytquant
 from . import qutils
+from . import sharded

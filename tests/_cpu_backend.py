@@ -1,0 +1,39 @@
+"""Test-only stand-in for the HIP binding: same call surface (parse_mode / cast_ / amax_ /
+cast_scaled_) on CPU tensors, implemented with the oracle.  Lets the multi-process collective
+logic of mpemu.sharded run over gloo in a container without GPUs.  Never imported by the product."""
+import numpy as np
+import torch
+
+import orc
+
+_FMT_NAMES = {v: k for k, v in orc.FMT.items()}
+_RM_NAMES = {v: k for k, v in orc.RMODE.items()}
+_MODE_PREFIX = {"BF16": "BFLOAT16", "FP16": "FLOAT16", "FP16_DAZ": "FLOAT16_DAZ"}
+
+
+def parse_mode(mode):
+    return orc.parse_mode(mode)
+
+
+def _mode(fmt, rmode):
+    f = _FMT_NAMES[fmt]
+    return "%s_%s" % (_MODE_PREFIX.get(f, f), _RM_NAMES[rmode])
+
+
+def cast_(src, dst, fmt, rmode, scale=1.0, seed=None, offset=None, elem_base=0):
+    y = orc.cast(src.numpy(), _mode(fmt, rmode), scale=scale, seed=seed or 0, offset=offset or 0,
+                 elem_base=elem_base)
+    dst.copy_(torch.from_numpy(y).view_as(dst))
+    return dst
+
+
+def amax_(src, amax_bits):
+    b = int(np.array([orc.amax(src.numpy())], dtype=np.float32).view(np.uint32)[0])
+    amax_bits[0] = max(int(amax_bits[0]), b)
+    return amax_bits
+
+
+def cast_scaled_(src, dst, fmt, rmode, amax_bits, flt_max, clamp=True, seed=None, offset=None, elem_base=0):
+    vmax = np.array([int(amax_bits[0])], dtype=np.uint32).view(np.float32)[0]
+    s = orc.scale_from_amax(vmax, flt_max, clamp=clamp)
+    return cast_(src, dst, fmt, rmode, scale=s, seed=seed, offset=offset, elem_base=elem_base)

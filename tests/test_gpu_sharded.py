@@ -1,0 +1,100 @@
+"""Sharded cast on the GPU: the HIP path must give the same bits whether a tensor is cast whole
+or as shards (elem_base carries the global index for the stochastic noise; per-tensor scaling
+uses the max-reduced amax word).  The 2-process case shares the one GPU of the test box and
+uses gloo for the 4-byte all-reduce (RCCL refuses two ranks on one device); the data path is
+the real HIP kernels."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import orc
+from _util import assert_bits_equal, mixed_inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _data(n):
+    x = mixed_inputs(n, seed=33)
+    x[~np.isfinite(x) | (np.abs(x) > 1000.0)] = 0.25
+    x[n - 7] = -2500.0
+    return x
+
+
+@pytest.mark.parametrize("mode,flt_max", [("E4M3_RNE", 448.0), ("E5M2_STOCHASTIC", 57344.0),
+                                          ("E3M4_STOCHASTIC", 30.0), ("BFLOAT16_STOCHASTIC", 1.0)])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_single_process_shards_equal_whole(mode, flt_max, world):
+    from mpemu.sharded import ShardedCaster, shard_bounds
+
+    n = (1 << 20) + 4321
+    x = _data(n)
+    t = torch.from_numpy(x).cuda()
+    sc = ShardedCaster()
+    whole_unscaled = sc.cast(t, mode, seed=3, offset=5)
+    word = sc.amax_words([t])
+    whole_scaled = sc.quantize_per_tensor(t, mode, flt_max, seed=3, offset=6, amax_word=word)
+    outs_u, outs_s, words = [], [], []
+    for r in range(world):
+        a, b = shard_bounds(n, world, r)
+        words.append(sc.amax_words([t[a:b]]))
+    gword = torch.stack(words).max(dim=0).values  # what the all-reduce(MAX) computes
+    assert torch.equal(gword, word)
+    for r in range(world):
+        a, b = shard_bounds(n, world, r)
+        outs_u.append(sc.cast(t[a:b], mode, elem_base=a, seed=3, offset=5))
+        outs_s.append(sc.quantize_per_tensor(t[a:b], mode, flt_max, elem_base=a, seed=3, offset=6, amax_word=gword))
+    assert torch.equal(torch.cat(outs_u).view(torch.int32), whole_unscaled.view(torch.int32))
+    assert torch.equal(torch.cat(outs_s).view(torch.int32), whole_scaled.view(torch.int32))
+    assert_bits_equal(whole_unscaled.cpu().numpy(), orc.cast(x, mode, seed=3, offset=5), mode)
+    if not mode.startswith("BFLOAT16"):
+        s = orc.scale_from_amax(orc.amax(x), flt_max)
+        assert_bits_equal(whole_scaled.cpu().numpy(), orc.cast(x, mode, scale=s, seed=3, offset=6), mode + " scaled")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, outdir):
+    for p in (os.path.join(ROOT, "fp8-emulation-toolkit_amd"), os.path.join(ROOT, "oracle"),
+              os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mpemu.sharded import ShardedCaster, shard_bounds
+
+    x = _data(n)
+    a, b = shard_bounds(n, world, rank)
+    shard = torch.from_numpy(x[a:b].copy()).cuda()
+    sc = ShardedCaster()
+    out = sc.quantize_per_tensor(shard, "E4M3_RNE", 448.0, elem_base=a)
+    out_sr = sc.quantize_per_tensor(shard, "E5M2_STOCHASTIC", 57344.0, elem_base=a, seed=8, offset=2)
+    torch.cuda.synchronize()
+    torch.save({"q": out.cpu(), "sr": out_sr.cpu()}, os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_one_gpu_global_amax(tmp_path):
+    n = 300000
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True) for r in range(world)]
+    x = _data(n)
+    s = orc.scale_from_amax(orc.amax(x), 448.0)
+    assert_bits_equal(np.concatenate([p["q"].numpy() for p in parts]), orc.cast(x, "E4M3_RNE", scale=s))
+    s5 = orc.scale_from_amax(orc.amax(x), 57344.0)
+    assert_bits_equal(np.concatenate([p["sr"].numpy() for p in parts]),
+                      orc.cast(x, "E5M2_STOCHASTIC", scale=s5, seed=8, offset=2))

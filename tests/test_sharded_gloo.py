@@ -1,0 +1,93 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run mpemu.sharded's collective logic (shard
+bounds, one all-reduce(MAX) of the amax word, global-index noise) with an oracle-backed stand-in
+for the HIP ops, and must reproduce the single-process result bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, outdir):
+    for p in (os.path.join(ROOT, "fp8-emulation-toolkit_amd"), os.path.join(ROOT, "oracle"),
+              os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import _cpu_backend
+    from _util import mixed_inputs
+    from mpemu.sharded import ShardedCaster, shard_bounds
+
+    x = mixed_inputs(n, seed=21)
+    x[~np.isfinite(x) | (np.abs(x) > 1000.0)] = 0.25   # finite amax; rank 1 holds the global maximum
+    x[n - 5] = 3000.0
+    a, b = shard_bounds(n, world, rank)
+    shard = torch.from_numpy(x[a:b].copy())
+    sc = ShardedCaster(backend=_cpu_backend)
+    res = {}
+    res["unscaled"] = sc.cast(shard, "E5M2_RNE", elem_base=a)
+    res["scaled"] = sc.quantize_per_tensor(shard, "E4M3_RNE", 448.0, elem_base=a)
+    res["scaled_sr"] = sc.quantize_per_tensor(shard, "E5M2_STOCHASTIC", 57344.0, elem_base=a, seed=9, offset=4)
+    words = sc.amax_words([shard, shard * 2.0])
+    res["words"] = words.clone()
+    torch.save({k: v for k, v in res.items()}, os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [10000, 4096 * 3 + 17])
+def test_two_rank_sharded_equals_single_process(tmp_path, n):
+    import orc
+    from _util import assert_bits_equal, mixed_inputs
+    from mpemu.sharded import shard_bounds
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True) for r in range(world)]
+
+    x = mixed_inputs(n, seed=21)
+    x[~np.isfinite(x) | (np.abs(x) > 1000.0)] = 0.25
+    x[n - 5] = 3000.0
+    cat = lambda k: np.concatenate([p[k].numpy() for p in parts])
+    assert_bits_equal(cat("unscaled"), orc.cast(x, "E5M2_RNE"), "unscaled")
+    s = orc.scale_from_amax(orc.amax(x), 448.0)
+    assert_bits_equal(cat("scaled"), orc.cast(x, "E4M3_RNE", scale=s), "scaled: every rank used the global amax")
+    s5 = orc.scale_from_amax(orc.amax(x), 57344.0)
+    assert_bits_equal(cat("scaled_sr"), orc.cast(x, "E5M2_STOCHASTIC", scale=s5, seed=9, offset=4),
+                      "stochastic: noise follows the global element index")
+    w0, w1 = parts[0]["words"], parts[1]["words"]
+    assert torch.equal(w0, w1)  # batched all-reduce: identical on every rank
+    assert w0.view(torch.float32)[0].item() == 3000.0 and w0.view(torch.float32)[1].item() == 6000.0
+    # the local maxima differ, so the agreement above really came from the collective
+    a0, b0 = shard_bounds(n, world, 0)
+    assert float(orc.amax(x[a0:b0])) != 3000.0
+
+
+def test_shard_bounds_cover_and_align():
+    from mpemu.sharded import SHARD_ALIGN, shard_bounds
+
+    for n in (0, 1, 2047, 2048, 2049, 10 ** 6 + 3, 1 << 31, (1 << 33) + 5):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                a, b = shard_bounds(n, world, r)
+                assert a == prev and a <= b <= n
+                assert a % SHARD_ALIGN == 0 or a == n
+                prev = b
+            assert prev == n
