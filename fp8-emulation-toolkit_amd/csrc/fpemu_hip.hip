@@ -436,14 +436,14 @@ int fpemu_cast_scaled(const void *in, void *out, uint64_t n, int dtype, int fmt,
 }
 
 int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
-                              float flt_max, uint32_t *amax_ws, uint64_t seed, uint64_t offset,
-                              void *stream) {
+                              float flt_max, int clamp, uint32_t *amax_ws, uint64_t seed,
+                              uint64_t offset, void *stream) {
   if (amax_ws == nullptr) return fail(FPEMU_EINVAL, "fpemu_quantize_per_tensor: null workspace");
   hipError_t e = hipMemsetAsync(amax_ws, 0, sizeof(uint32_t), (hipStream_t)stream);
   if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
   int rc = fpemu_amax(in, n, dtype, amax_ws, stream);
   if (rc != FPEMU_OK) return rc;
-  return fpemu_cast_scaled(in, out, n, dtype, fmt, rmode, amax_ws, flt_max, 1, seed, offset, 0, stream);
+  return fpemu_cast_scaled(in, out, n, dtype, fmt, rmode, amax_ws, flt_max, clamp, seed, offset, 0, stream);
 }
 
 }  // extern "C"

@@ -57,7 +57,7 @@ def lib():
         L.fpemu_cast_scaled.restype = i32
         L.fpemu_cast_scaled.argtypes = [vp, vp, u64, i32, i32, i32, vp, f32, i32, u64, u64, u64, vp]
         L.fpemu_quantize_per_tensor.restype = i32
-        L.fpemu_quantize_per_tensor.argtypes = [vp, vp, u64, i32, i32, i32, f32, vp, u64, u64, vp]
+        L.fpemu_quantize_per_tensor.argtypes = [vp, vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, vp]
         L.fpemu_set_max_blocks.restype = None
         L.fpemu_set_max_blocks.argtypes = [i32]
         if L.fpemu_abi_version() != 1:
@@ -168,7 +168,7 @@ def cast_scaled_(src, dst, fmt, rmode, amax_bits, flt_max, clamp=True, seed=None
     return dst
 
 
-def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None):
+def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None, clamp=True):
     """Fused amax -> device-side scale -> cast (qutils.py:282-287), no host sync."""
     _require_device(src)
     _require_device(dst, "output")
@@ -177,7 +177,7 @@ def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None):
     with torch.cuda.device_of(src):
         _check(lib().fpemu_quantize_per_tensor(src.data_ptr(), dst.data_ptr(), src.numel(),
                                                _dtype_id(src), fmt, rmode, float(flt_max),
-                                               amax_ws.data_ptr(), _seed, _next_offset(rmode),
+                                               int(bool(clamp)), amax_ws.data_ptr(), _seed, _next_offset(rmode),
                                                _stream(src)))
     return dst
 

@@ -207,7 +207,7 @@ class _ScaledCast(torch.autograd.Function):
             torch.distributed.all_reduce(ws, op=torch.distributed.ReduceOp.MAX, group=_amax_group)
             _hip.cast_scaled_(src, dst, fmt, rmode, ws, flt_max, clamp=clamp)
         else:
-            _hip.quantize_per_tensor_(src, dst, fmt, rmode, flt_max)
+            _hip.quantize_per_tensor_(src, dst, fmt, rmode, flt_max, clamp=clamp)
         if inplace:
             if src is not tensor:
                 tensor.copy_(src)

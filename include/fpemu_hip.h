@@ -114,12 +114,13 @@ int fpemu_cast_scaled(const void *in, void *out, uint64_t n, int dtype, int fmt,
                       const uint32_t *amax_bits, float flt_max, int clamp, uint64_t seed,
                       uint64_t offset, uint64_t elem_base, void *stream);
 
-/* quantize_tensor's per-tensor "max" branch in one call (qutils.py:282-287): zero the
- * workspace word, amax, device-side scale, cast.  amax_ws: 4 bytes of device memory owned by
- * the caller (holds the amax bits afterwards). */
+/* quantize_tensor's per-tensor "max" branch in one call (qutils.py:282-287; clamp=0 gives the
+ * fine-grained branch's unclamped scale, qutils.py:328-332): zero the workspace word, amax,
+ * device-side scale, cast.  amax_ws: 4 bytes of device memory owned by the caller (holds the
+ * amax bits afterwards). */
 int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
-                              float flt_max, uint32_t *amax_ws, uint64_t seed, uint64_t offset,
-                              void *stream);
+                              float flt_max, int clamp, uint32_t *amax_ws, uint64_t seed,
+                              uint64_t offset, void *stream);
 
 /* Launch-geometry override for benchmarking sweeps: blocks per launch cap (0 = default).
  * Affects performance only, never results. */

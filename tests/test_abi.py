@@ -66,4 +66,4 @@ def test_argument_errors_without_gpu():
     assert L.fpemu_amax(None, 4, 0, None, None) == -1
     assert L.fpemu_amax(16, 0, 0, 16, None) == 0
     assert L.fpemu_cast_scaled(16, 16, 4, 0, 1, 1, None, 448.0, 1, 0, 0, 0, None) == -1
-    assert L.fpemu_quantize_per_tensor(16, 16, 4, 0, 1, 1, 448.0, None, 0, 0, None) == -1
+    assert L.fpemu_quantize_per_tensor(16, 16, 4, 0, 1, 1, 448.0, 1, None, 0, 0, None) == -1

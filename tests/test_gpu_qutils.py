@@ -1,0 +1,107 @@
+"""The Python callers of the cast on the GPU (FPEmuOp, fpemu_device_fn, quantize_tensor) against
+outputs of the REFERENCE's own Python package (tests/golden/qtensor.npz, produced by running
+mpemu.qutils.quantize_tensor of /root/reference on CPU)."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from _util import assert_bits_equal, mixed_inputs, npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_quantize_tensor_vs_reference_python():
+    from mpemu import qutils
+
+    g = npz("qtensor.npz")
+    n = 0
+    for key in g["names"]:
+        tname, dtype, scheme, scaling, gs, inplace = str(key).split("|")
+        x = torch.from_numpy(g["in/" + tname].view(np.float32).copy()).to(DEV)
+        x0 = x.clone()
+        cfg = qutils.TensorQuantConfig(dtype, scheme, scaling, int(gs))
+        q = qutils.quantize_tensor(x, cfg, None, inplace=bool(int(inplace)))
+        assert_bits_equal(q.cpu().numpy(), g["out/" + str(key)], str(key))
+        if int(inplace):
+            assert q.data_ptr() == x.data_ptr()
+        else:
+            assert torch.equal(x.view(torch.int32), x0.view(torch.int32)), "input clobbered: " + str(key)
+        n += 1
+    assert n >= 120
+
+
+def test_fpemu_op_semantics():
+    from mpemu.pytquant import fpemu_cuda
+    from mpemu.qutils import fpemu_device_fn
+
+    x = torch.from_numpy(mixed_inputs(5000, seed=4)).to(DEV)
+    xn = x.cpu().numpy()
+    y = fpemu_cuda.FPEmuOp.apply(x, "E4M3_RNE")                       # defaults: out-of-place, scale 1
+    assert y.data_ptr() != x.data_ptr()
+    assert_bits_equal(y.cpu().numpy(), orc.cast(xn, "E4M3_RNE"))
+    assert fpemu_cuda.FPEmuOp.apply(x, "NONE") is x or fpemu_cuda.FPEmuOp.apply(x, "NONE").data_ptr() == x.data_ptr()
+    z = x.clone()
+    r = fpemu_device_fn(z, "E5M2_RNE")                                # fpemu_device_fn defaults to inplace
+    assert r.data_ptr() == z.data_ptr()
+    assert_bits_equal(z.cpu().numpy(), orc.cast(xn, "E5M2_RNE"))
+    # scale given as a 0-dim device tensor (what the reference's quantize_tensor passes)
+    s = torch.tensor(3.5, device=DEV)
+    y = fpemu_device_fn(x, "E3M4_RNE", inplace=False, scale=s)
+    assert_bits_equal(y.cpu().numpy(), orc.cast(xn, "E3M4_RNE", scale=3.5))
+    # non-contiguous input: cast runs on a contiguous copy, result has the logical layout
+    m = x[:4900].view(70, 70).t()
+    y = fpemu_cuda.FPEmuOp.apply(m, "E4M3_RNE", False, 1.0)
+    assert_bits_equal(y.cpu().numpy(), orc.cast(m.cpu().contiguous().numpy(), "E4M3_RNE"))
+    # unknown mode raises (the reference silently returns zeros)
+    with pytest.raises(ValueError):
+        fpemu_cuda.FPEmuOp.apply(x, "E4M3_XYZ")
+    # straight-through estimator
+    w = x.clone().requires_grad_(True)
+    out = fpemu_cuda.FPEmuOp.apply(w, "E5M2_STOCHASTIC", False, 1.0)
+    (out * 2).sum().backward()
+    assert torch.equal(w.grad, torch.full_like(w, 2.0))
+
+
+def test_sparse_tensors():
+    from mpemu.pytquant import fpemu_cuda
+
+    d = torch.from_numpy(mixed_inputs(64 * 64, seed=6)).view(64, 64)
+    d[d.abs() < 1.0] = 0
+    d[~torch.isfinite(d)] = 0
+    sp = d.to_sparse().to(DEV)
+    out = fpemu_cuda.FPEmuOp.apply(sp, "E4M3_RNE", False, 1.0)
+    assert out.is_sparse
+    assert_bits_equal(out.to_dense().cpu().numpy(), orc.cast(d.numpy(), "E4M3_RNE"))
+
+
+def test_stochastic_stream_state():
+    from mpemu.pytquant.hip import fpemu as F
+
+    x = torch.full((1 << 16,), 1.1, device=DEV)
+    F.manual_seed(123)
+    a = F.FPEmuOp.apply(x, "E5M2_STOCHASTIC")
+    b = F.FPEmuOp.apply(x, "E5M2_STOCHASTIC")       # next call: next offset, different draws
+    F.manual_seed(123)
+    a2 = F.FPEmuOp.apply(x, "E5M2_STOCHASTIC")
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    st = F.get_rng_state()
+    c = F.FPEmuOp.apply(x, "E5M2_STOCHASTIC")
+    F.set_rng_state(st)
+    assert torch.equal(c, F.FPEmuOp.apply(x, "E5M2_STOCHASTIC"))
+    assert abs(a.mean().item() - 1.1) < 2e-3       # unbiased: mean(1.1) ~ 1.1 (reference scalar: 1.0997)
+
+
+def test_half_and_bfloat16_tensors_through_qutils():
+    from mpemu import qutils
+
+    x = torch.randn(4096 + 3, device=DEV)
+    for dt in (torch.float16, torch.bfloat16):
+        xs = x.to(dt)
+        q = qutils.quantize_tensor(xs, qutils.TensorQuantConfig("e4m3", "rne", "per-tensor"), None)
+        assert q.dtype == dt
+        ref = xs.float().cpu().numpy()
+        s = orc.scale_from_amax(orc.amax(ref), 448.0)
+        want = torch.from_numpy(orc.cast(ref, "E4M3_RNE", scale=s)).to(dt)
+        assert torch.equal(q.cpu().view(torch.int16), want.view(torch.int16))
