@@ -249,6 +249,85 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// rows: per-row amax -> scale -> cast of a contiguous [rows, cols] buffer in ONE launch.
+// Replaces the reference's Python loop over channels (qutils.py:289-311: per row a torch.max, a
+// host-synchronising scale computation and one cast launch) and, with clamp = 0 and
+// rows = out_channels x groups, its fine-grained loop (qutils.py:313-337).
+// One 256-thread block per row: pass 1 reduces |x| over the row (plain loads, so the row stays
+// in L2 for pass 2), wave64 butterfly + one LDS word per wave, every thread derives the row's
+// scale, pass 2 re-reads and casts.  VEC = rows are 16-byte aligned (cols % V == 0).
+// Stochastic noise: row r is "call offset + r", element index = column, exactly what a loop of
+// per-row casts with consecutive offsets draws.
+// ---------------------------------------------------------------------------------------------
+template <int FMT, int RM, int DT, bool VEC>
+__global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out_, uint64_t cols,
+                                                      float flt_max, int clamp, uint64_t seed,
+                                                      uint64_t offset) {
+  constexpr unsigned V = Storage<DT>::V;
+  constexpr bool SR = (RM == STOCHASTIC);
+  using elem_t = typename Storage<DT>::elem;
+  const uint64_t row = blockIdx.x;
+  const elem_t *ein = reinterpret_cast<const elem_t *>(in_) + row * cols;
+  elem_t *eout = reinterpret_cast<elem_t *>(out_) + row * cols;
+  const u32x4 *vin = reinterpret_cast<const u32x4 *>(ein);
+  u32x4 *vout = reinterpret_cast<u32x4 *>(eout);
+  const uint64_t nvec = VEC ? cols / V : 0;
+
+  uint32_t m = 0u;
+  for (uint64_t i = threadIdx.x; i < nvec; i += kBlock) {
+    const u32x4 v = vin[i];
+#pragma unroll
+    for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, v[j]);
+  }
+  for (uint64_t e = nvec * V + threadIdx.x; e < cols; e += kBlock) {
+    if constexpr (DT == FPEMU_F32) m = absmax_word<DT>(m, f2u(ein[e]));
+    else m = absmax_word<DT>(m, (uint32_t)ein[e]);
+  }
+  m = wave_max_u32(m);
+  __shared__ uint32_t part[kWavesPerBlock];
+  if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  uint32_t r = part[0];
+#pragma unroll
+  for (int w = 1; w < kWavesPerBlock; w++) r = r > part[w] ? r : part[w];
+  if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
+  else if constexpr (DT == FPEMU_BF16) r = r << 16;
+  const float scale = scale_from_amax(r, flt_max, clamp != 0);
+  const float rcp = scale_reciprocal(scale);
+  const uint64_t roff = offset + row;
+
+  for (uint64_t i = threadIdx.x; i < nvec; i += kBlock) {
+    const u32x4 v = vin[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if constexpr (DT == FPEMU_F32) {
+        uint32_t rnd = 0u;
+        if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, i * V + j);
+        o[j] = f2u(cast_one<FMT, RM>(u2f(v[j]), scale, rcp, rnd));
+      } else {
+        uint32_t r0 = 0u, r1 = 0u;
+        if constexpr (SR) {
+          r0 = rand_bits_elem<FMT, V>(seed, roff, i * V + 2 * j);
+          r1 = rand_bits_elem<FMT, V>(seed, roff, i * V + 2 * j + 1);
+        }
+        const float y0 = cast_one<FMT, RM>(load_elem16<DT>(v[j] & 0xFFFFu), scale, rcp, r0);
+        const float y1 = cast_one<FMT, RM>(load_elem16<DT>(v[j] >> 16), scale, rcp, r1);
+        o[j] = (store_elem16<DT>(y0) & 0xFFFFu) | (store_elem16<DT>(y1) << 16);
+      }
+    }
+    vout[i] = o;
+  }
+  for (uint64_t e = nvec * V + threadIdx.x; e < cols; e += kBlock) {
+    uint32_t rnd = 0u;
+    if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, e);
+    if constexpr (DT == FPEMU_F32) eout[e] = cast_one<FMT, RM>(ein[e], scale, rcp, rnd);
+    else eout[e] = (elem_t)store_elem16<DT>(cast_one<FMT, RM>(load_elem16<DT>(ein[e]), scale, rcp, rnd));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host side: dispatch tables and launch geometry.
 // ---------------------------------------------------------------------------------------------
@@ -268,6 +347,30 @@ template <int DT> cast_fn pick_cast(int fmt, int rm) {
   FPEMU_CASE(FP16_DAZ, RNE)
 #undef FPEMU_CASE
   return nullptr;
+}
+
+typedef void (*rows_fn)(const void *, void *, uint64_t, float, int, uint64_t, uint64_t);
+
+template <int DT, bool VEC> rows_fn pick_rows(int fmt, int rm) {
+#define FPEMU_CASE(F, R) \
+  if (fmt == F && rm == R) return rows_kernel<F, R, DT, VEC>;
+  FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
+  FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
+  FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
+  FPEMU_CASE(E5M2_DAZ, RNTZ)
+  FPEMU_CASE(E4M3, RTZ) FPEMU_CASE(E4M3, RNE) FPEMU_CASE(E4M3, STOCHASTIC)
+  FPEMU_CASE(E3M4, RTZ) FPEMU_CASE(E3M4, RNE) FPEMU_CASE(E3M4, STOCHASTIC)
+#undef FPEMU_CASE
+  return nullptr;  // BF16 / FP16 take no scale: per-row scaling is meaningless for them
+}
+
+rows_fn pick_rows_dt(int dtype, bool vec, int fmt, int rm) {
+  switch (dtype) {
+    case FPEMU_F32: return vec ? pick_rows<FPEMU_F32, true>(fmt, rm) : pick_rows<FPEMU_F32, false>(fmt, rm);
+    case FPEMU_F16: return vec ? pick_rows<FPEMU_F16, true>(fmt, rm) : pick_rows<FPEMU_F16, false>(fmt, rm);
+    case FPEMU_BF16: return vec ? pick_rows<FPEMU_BF16, true>(fmt, rm) : pick_rows<FPEMU_BF16, false>(fmt, rm);
+    default: return nullptr;
+  }
 }
 
 cast_fn pick_cast_dt(int dtype, int fmt, int rm) {
@@ -444,6 +547,27 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
   int rc = fpemu_amax(in, n, dtype, amax_ws, stream);
   if (rc != FPEMU_OK) return rc;
   return fpemu_cast_scaled(in, out, n, dtype, fmt, rmode, amax_ws, flt_max, clamp, seed, offset, 0, stream);
+}
+
+int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt,
+                        int rmode, float flt_max, int clamp, uint64_t seed, uint64_t offset,
+                        void *stream) {
+  if (rows == 0 || cols == 0) return FPEMU_OK;
+  if (in == nullptr || out == nullptr) return fail(FPEMU_EINVAL, "fpemu_quantize_rows: null buffer");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_quantize_rows: bad dtype id");
+  if (rows > 0x7FFFFFFFull) return fail(FPEMU_EINVAL, "fpemu_quantize_rows: more than 2^31-1 rows");
+  const unsigned es = elem_size(dtype);
+  if (((uintptr_t)in % es) || ((uintptr_t)out % es))
+    return fail(FPEMU_EALIGN, "fpemu_quantize_rows: buffer not aligned to its element size");
+  const bool vec = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % vec_elems(dtype)) == 0;
+  rows_fn fn = pick_rows_dt(dtype, vec, fmt, rmode);
+  if (fn == nullptr)
+    return fail(FPEMU_EINVAL, "fpemu_quantize_rows: format / rounding-mode pair takes no scale or is not defined");
+  hipLaunchKernelGGL(fn, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, in, out, cols,
+                     flt_max, clamp, seed, offset);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  return FPEMU_OK;
 }
 
 }  // extern "C"

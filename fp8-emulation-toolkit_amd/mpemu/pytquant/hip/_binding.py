@@ -58,6 +58,8 @@ def lib():
         L.fpemu_cast_scaled.argtypes = [vp, vp, u64, i32, i32, i32, vp, f32, i32, u64, u64, u64, vp]
         L.fpemu_quantize_per_tensor.restype = i32
         L.fpemu_quantize_per_tensor.argtypes = [vp, vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, vp]
+        L.fpemu_quantize_rows.restype = i32
+        L.fpemu_quantize_rows.argtypes = [vp, vp, u64, u64, i32, i32, i32, f32, i32, u64, u64, vp]
         L.fpemu_set_max_blocks.restype = None
         L.fpemu_set_max_blocks.argtypes = [i32]
         if L.fpemu_abi_version() != 1:
@@ -179,6 +181,25 @@ def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None, clamp=True
                                                _dtype_id(src), fmt, rmode, float(flt_max),
                                                int(bool(clamp)), amax_ws.data_ptr(), _seed, _next_offset(rmode),
                                                _stream(src)))
+    return dst
+
+
+def quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=True):
+    """Per-row amax -> scale -> cast of a contiguous buffer viewed as [rows, numel/rows], one launch
+    (the per-channel / fine-grained policies of qutils.py:289-337)."""
+    global _offset
+    _require_device(src)
+    _require_device(dst, "output")
+    n = src.numel()
+    if rows <= 0 or n % rows:
+        raise ValueError("fpemu: %d elements do not split into %d rows" % (n, rows))
+    off = _offset
+    if rmode == STOCHASTIC:
+        _offset += rows  # one call offset per row, as a loop of per-row casts would consume
+    with torch.cuda.device_of(src):
+        _check(lib().fpemu_quantize_rows(src.data_ptr(), dst.data_ptr(), rows, n // rows, _dtype_id(src),
+                                         fmt, rmode, float(flt_max), int(bool(clamp)), _seed, off,
+                                         _stream(src)))
     return dst
 
 

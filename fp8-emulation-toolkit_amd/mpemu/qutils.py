@@ -221,7 +221,17 @@ class _ScaledCast(torch.autograd.Function):
 
 
 def _hip_quantize_rows(src, dst, fmt, rmode, flt_max, rows, clamp):
-    """Per-row amax/scale/cast of a contiguous [rows, cols] buffer, no host sync."""
+    """Per-row amax/scale/cast of a contiguous [rows, cols] buffer, no host sync.
+
+    One launch of the rows kernel (one workgroup per row).  A few very long rows would leave most
+    of the chip idle that way, so those go row by row through the full-width amax / cast kernels."""
+    if fmt in (_hip.FMT_BF16, _hip.FMT_FP16, _hip.FMT_FP16_DAZ):
+        _hip.cast_(src, dst, fmt, rmode)  # these formats take no scale (cpp/fpemu_impl.cpp:1933-1957)
+        return
+    cols = src.numel() // rows
+    if rows >= 64 or cols <= (1 << 16):
+        _hip.quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=clamp)
+        return
     s2, d2 = src.view(rows, -1), dst.view(rows, -1)
     ws = torch.zeros(rows, dtype=torch.int32, device=src.device)
     for r in range(rows):
@@ -286,6 +296,17 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
         return tensor if inplace else tensor_q
 
     if qtconfig.fine_grained is True:
+        if (qtconfig.scaling_method == "max" and on_device and tensor.dim() >= 2 and tensor.is_contiguous()
+                and tensor.numel() > 0):
+            # groups are torch.chunk pieces of dim 1; when they are equal-sized every (out-channel,
+            # group) pair is one contiguous row and the whole tensor is one rows-kernel launch
+            in_ch = tensor.shape[1]
+            chunks = max(1, int(in_ch / qtconfig.group_size))
+            size = -(-in_ch // chunks)
+            if in_ch % size == 0:
+                rows = tensor.shape[0] * (in_ch // size)
+                q = _ScaledCast.apply(tensor.detach(), mode, inplace, qtconfig.get_flt_max(), rows, False)
+                return tensor if inplace else q
         tensor_q = None if inplace else torch.zeros_like(tensor)
         for k in range(tensor.shape[0]):
             crs = tensor.select(0, k).detach()

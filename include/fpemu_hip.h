@@ -122,6 +122,16 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
                               float flt_max, int clamp, uint32_t *amax_ws, uint64_t seed,
                               uint64_t offset, void *stream);
 
+/* Per-row amax -> scale -> cast of a contiguous [rows, cols] buffer in one launch: row r gets
+ * scale_r = fp32(fp32(1/max|row r|) * flt_max) (+ clamp rule when clamp != 0).  Replaces the Python
+ * loops of quantize_tensor's per-channel branch (qutils.py:289-311, clamp = 1, rows = shape[0]) and
+ * fine-grained branch (qutils.py:313-337, clamp = 0, rows = out_channels x groups when the groups are
+ * equal-sized).  Results equal a loop of fpemu_quantize_per_tensor over the rows with stochastic
+ * offsets offset, offset+1, ...  Formats without a scale (BF16 / FP16) are rejected. */
+int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt,
+                        int rmode, float flt_max, int clamp, uint64_t seed, uint64_t offset,
+                        void *stream);
+
 /* Launch-geometry override for benchmarking sweeps: blocks per launch cap (0 = default).
  * Affects performance only, never results. */
 void fpemu_set_max_blocks(int max_blocks);

@@ -264,3 +264,55 @@ def test_device_scale_random_amax_sweep(hip):
         hip.quantize_per_tensor_(t, o, fmt, rm, 448.0)
         s = orc.scale_from_amax(orc.amax(x), 448.0)
         assert_bits_equal(o.cpu().numpy(), orc.cast(x, "E4M3_RNE", scale=s), "amax=%r" % orc.amax(x))
+
+
+# ------------------------------------------------------------------------------------------
+# rows kernel: per-channel / fine-grained scaling in one launch
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 7), (64, 147), (17, 1024), (768, 768), (5, 70001),
+                                       (3072, 768), (2, 262144)])
+@pytest.mark.parametrize("mode,clamp", [("E4M3_RNE", True), ("E5M2_RNE", True), ("E3M4_RNE", False),
+                                        ("E5M2_STOCHASTIC", True), ("E4M3_RTZ", False)])
+def test_rows_kernel_vs_oracle_loop(hip, rows, cols, mode, clamp):
+    fmt, rm = hip.parse_mode(mode)
+    fmax = FLT_MAX[mode.split("_")[0]]
+    rng = np.random.default_rng(rows * 131 + cols)
+    x = (rng.standard_normal((rows, cols)) * np.exp(rng.standard_normal((rows, 1)) * 6)).astype(np.float32)
+    if rows > 2:
+        x[1] = 0.0                      # all-zero row: vmax = 0 -> inf -> clamp (or inf scale unclamped)
+        x[2, 0] = 1e-41                 # denormal maximum candidates
+    t = torch.from_numpy(x).to(DEV)
+    o = torch.empty_like(t)
+    hip.set_rng_state((77, 1000))
+    hip.quantize_rows_(t, o, rows, fmt, rm, fmax, clamp=clamp)
+    got = o.cpu().numpy()
+    sel = range(rows) if rows <= 64 else list(range(0, rows, 97)) + [rows - 1]
+    for r in sel:
+        s = orc.scale_from_amax(orc.amax(x[r]), fmax, clamp=clamp)
+        want = orc.cast(x[r], mode, scale=s, seed=77, offset=1000 + r)
+        assert_bits_equal(got[r], want, "%s row %d" % (mode, r), nan_payload_ok=True)
+    if rm == hip.STOCHASTIC:
+        assert hip.get_rng_state() == (77, 1000 + rows)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_rows_kernel_16bit_storage(hip, dt):
+    fmt, rm = hip.parse_mode("E4M3_RNE")
+    for rows, cols in ((9, 33), (40, 256)):
+        t = (torch.randn(rows, cols, device=DEV) * 3).to(dt)
+        o = torch.empty_like(t)
+        hip.quantize_rows_(t, o, rows, fmt, rm, 448.0)
+        x = t.float().cpu().numpy()
+        for r in range(rows):
+            s = orc.scale_from_amax(orc.amax(x[r]), 448.0)
+            want = torch.from_numpy(orc.cast(x[r], "E4M3_RNE", scale=s)).to(dt)
+            assert torch.equal(o[r].cpu().view(torch.int16), want.view(torch.int16)), (dt, rows, cols, r)
+
+
+def test_rows_kernel_rejects_scale_free_formats(hip):
+    t = torch.randn(4, 8, device=DEV)
+    fmt, rm = hip.parse_mode("BFLOAT16_RNE")
+    with pytest.raises(ValueError):
+        hip.quantize_rows_(t, torch.empty_like(t), 4, fmt, rm, 1.0)
+    with pytest.raises(ValueError):
+        hip.quantize_rows_(t, torch.empty_like(t), 5, *hip.parse_mode("E4M3_RNE"), 448.0)
