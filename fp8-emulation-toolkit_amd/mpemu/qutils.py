@@ -329,3 +329,129 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
         return tensor if inplace else tensor_q
 
     return fpemu_device_fn(tensor, mode, inplace=inplace)
+
+
+# ---------------------------------------------------------------------------------------------
+# Model-level configuration and the module hooks (reference qutils.py:351-365, 458-475, 478-660).
+# The hooks only decide WHICH tensors are cast with WHICH config; every cast goes through
+# quantize_tensor above, i.e. the HIP kernels.  Out of scope here (not on the cast path): the
+# stats collectors, tensor dumps and tensorboard plumbing of the reference (flags are accepted
+# and ignored), and the CPU-only op monkey-patching (`patch_ops`, cmodel).
+# ---------------------------------------------------------------------------------------------
+def get_or_update_model_quant_config_dict(model, filter_module_types, mod_qconfig, prefix="",
+                                          model_qconfig_dict=None, override=False, exempt_modules=[]):
+    """name -> deep copy of mod_qconfig for every module whose exact type is listed."""
+    if model_qconfig_dict is None:
+        model_qconfig_dict = OrderedDict()
+    for name, module in model.named_modules():
+        fname = prefix + name
+        listed = type(module) in filter_module_types
+        if listed and fname not in exempt_modules:
+            if override or fname not in model_qconfig_dict:
+                model_qconfig_dict[fname] = copy.deepcopy(mod_qconfig)
+        elif not listed and fname in model_qconfig_dict:
+            model_qconfig_dict.pop(fname)
+    return model_qconfig_dict
+
+
+def get_quantization_parameters(tensor, qtconfig):
+    """The floating-point formats are stateless: no parameters (qutils.py:448-456)."""
+    return None
+
+
+def quantize_weights_of_a_module(module, wt_qconfig, name=""):
+    module.weight.data.copy_(quantize_tensor(module.weight.data, wt_qconfig, None))
+
+
+def quantize_model_weights(model, model_qconfig_dict):
+    for name, module in model.named_modules():
+        cfg = model_qconfig_dict.get(name)
+        if cfg is not None and cfg.wt_qconfig is not None:
+            quantize_weights_of_a_module(module, cfg.wt_qconfig, name=name)
+
+
+def _active(qtconfig):
+    return qtconfig is not None and qtconfig.is_enabled
+
+
+def quantize_module_weights_and_inputs(self, input):
+    """forward-pre hook: weights in place, then every positional input out of place."""
+    qc = self.qconfig
+    if qc.patch_ops and qc.patch_impl not in ("None", "NONE") and any(True for _ in self.parameters()):
+        if not next(self.parameters()).is_cuda:
+            raise NotImplementedError("mpemu (MI355X build): op patching with the CPU cmodel is not available")
+    keeps_master = qc.wt_qconfig is not None and (qc.wt_qconfig.dtype in ["bfloat16"] or qc.device == 'cpu')
+    if keeps_master:
+        qc.weight_master = copy.deepcopy(self.weight.data)
+    if qc.sparse_config is not None and qc.sparse_config.weight and type(self) in [torch.nn.Conv2d, torch.nn.Linear]:
+        self.weight.data = qc.sparse_config.sparsify_weight_tensor(self.weight.data)
+    if _active(qc.wt_qconfig):
+        self.weight.data = quantize_tensor(self.weight.data, qc.wt_qconfig, self.qparams.wt_qparams, inplace=True)
+    if _active(qc.iact_qconfig):
+        input = tuple(quantize_tensor(t, qc.iact_qconfig, None, inplace=False) for t in input)
+    return input
+
+
+def quantize_module_gradient(self, grad_input, grad_output):
+    """full-backward hook: input gradients out of place; restores a master weight copy if kept."""
+    qc = self.qconfig
+    if qc.sparse_config is not None and qc.sparse_config.ingrad:
+        grad_input = tuple(qc.sparse_config.sparsify_ingrad_tensor(g) for g in grad_input)
+    if _active(qc.igrad_qconfig):
+        grad_input = tuple(g if g is None else quantize_tensor(g, qc.igrad_qconfig, self.qparams.igrad_qparams,
+                                                                inplace=False) for g in grad_input)
+    if qc.wt_qconfig is not None and (qc.wt_qconfig.dtype in ["bfloat16"] or qc.device == 'cpu'):
+        self.weight.data = copy.deepcopy(qc.weight_master)
+    return grad_input
+
+
+def quantize_module_output(self, input, output):
+    """forward hook: registers the output-gradient hook, then casts the output in place."""
+    qc = self.qconfig
+    qc.register_output_grad_hook(output)
+    if _active(qc.oact_qconfig):
+        output = quantize_tensor(output, qc.oact_qconfig, self.qparams.oact_qparams, inplace=True)
+    return output
+
+
+def add_quantization_hooks(model, model_qconfig_dict, is_training=False):
+    handles = []
+    for name, module in model.named_modules():
+        if name not in model_qconfig_dict:
+            continue
+        handles.append(module.register_forward_pre_hook(quantize_module_weights_and_inputs))
+        handles.append(module.register_forward_hook(quantize_module_output))
+        if is_training:
+            if module.qconfig.igrad_qconfig is not None:
+                handles.append(module.register_full_backward_hook(quantize_module_gradient))
+            module.qconfig.register_weight_grad_hook(module)
+    return handles
+
+
+def reset_quantization_setup(model, model_qconfig_dict):
+    """Attach .name / .qconfig / .qparams to every configured module."""
+    for name, module in model.named_modules():
+        if name in model_qconfig_dict:
+            module.name = name
+            module.qconfig = copy.deepcopy(model_qconfig_dict[name])
+            module.qparams = ModuleQuantParams()
+
+
+def _set_flag(model, model_qconfig_dict, attr, value):
+    for name, module in model.named_modules():
+        if name in model_qconfig_dict:
+            cfg = getattr(module.qconfig, attr)
+            if cfg is not None:
+                cfg.is_enabled = value
+
+
+def set_quantize_weights_flag(model, model_qconfig_dict, set_value):
+    _set_flag(model, model_qconfig_dict, "wt_qconfig", set_value)
+
+
+def set_quantize_outputs_flag(model, model_qconfig_dict, set_value):
+    _set_flag(model, model_qconfig_dict, "oact_qconfig", set_value)
+
+
+def set_quantize_inputs_flag(model, model_qconfig_dict, set_value):
+    _set_flag(model, model_qconfig_dict, "iact_qconfig", set_value)

@@ -16,6 +16,7 @@ Fixtures (all loadable with numpy.load(allow_pickle=False) / json):
   testpy64.json   the 64 edge-case inputs the reference's own pytquant/test.py holds x modes
   sr_hist.json    scalar-reference stochastic-rounding round-up counts (distribution pin)
   qtensor.npz     reference qutils.quantize_tensor (per-tensor / per-channel / fine-grained / mean)
+  models.npz      reference mpt_emu.quantize_model / scale_shift on tiny seeded models
 """
 import json
 import os
@@ -208,8 +209,78 @@ def gen_qtensor():
     np.savez_compressed(os.path.join(HERE, "qtensor.npz"), **out)
 
 
+def _tiny_models():
+    torch.manual_seed(1234)
+    mlp = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.ReLU(), torch.nn.Linear(64, 24))
+    conv = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                               torch.nn.Conv2d(8, 6, 3))
+    with torch.no_grad():
+        conv[1].running_mean.copy_(torch.randn(8) * 0.3)
+        conv[1].running_var.copy_(torch.rand(8) + 0.5)
+        conv[1].weight.copy_(torch.randn(8))
+        conv[1].bias.copy_(torch.randn(8))
+    x_mlp = torch.randn(16, 40) * 2.0
+    x_conv = torch.randn(4, 3, 10, 10)
+    return mlp, conv, x_mlp, x_conv
+
+
+def gen_models():
+    """Reference mpt_emu.quantize_model / scale_shift on tiny seeded models (CPU).  Weights after
+    quantisation and the tensors entering each hooked module are exact pins; layer outputs go
+    through the host BLAS and are compared with a tolerance on the GPU side."""
+    import copy
+
+    build_ref.import_reference_package("scalar")
+    from mpemu import mpt_emu, scale_shift
+
+    mlp, conv, x_mlp, x_conv = _tiny_models()
+    out = {"x_mlp": x_mlp.numpy().view(np.uint32), "x_conv": x_conv.numpy().view(np.uint32)}
+    for k, v in mlp.state_dict().items():
+        out["mlp_init/" + k] = v.numpy().view(np.uint32)
+    for k, v in conv.state_dict().items():
+        if v.dtype == torch.float32:
+            out["conv_init/" + k] = v.numpy().view(np.uint32)
+    for dtype in ("e4m3", "e5m2", "e3m4", "hybrid"):
+        for calibrate in (False, True):
+            m = copy.deepcopy(mlp).eval()
+            m, emu = mpt_emu.quantize_model(m, dtype=dtype, calibrate=calibrate, device="cpu")
+            seen = {}
+
+            def grab(mod, inp, tag):
+                seen[tag] = inp[0].detach().clone()
+
+            h0 = m[0].register_forward_hook(lambda mod, i, o: grab(mod, i, "in0"))
+            h2 = m[2].register_forward_hook(lambda mod, i, o: grab(mod, i, "in2"))
+            with torch.no_grad():
+                y = m(x_mlp.clone())
+            tag = "mlp/%s/%d/" % (dtype, int(calibrate))
+            out[tag + "w0"] = m[0].weight.detach().numpy().view(np.uint32)
+            out[tag + "w2"] = m[2].weight.detach().numpy().view(np.uint32)
+            out[tag + "in0"] = seen["in0"].numpy().view(np.uint32)
+            out[tag + "in2"] = seen["in2"].numpy().view(np.uint32)
+            out[tag + "y"] = y.numpy().view(np.uint32)
+            h0.remove(); h2.remove()
+    c = copy.deepcopy(conv).eval()
+    with torch.no_grad():
+        y_bn = c(x_conv)
+    c2 = scale_shift.replace_batchnorms_with_scaleshifts(copy.deepcopy(conv).eval())
+    with torch.no_grad():
+        y_ss = c2(x_conv)
+    out["conv/ss_weight"] = c2[1].weight.detach().numpy().view(np.uint32)
+    out["conv/ss_bias"] = c2[1].bias.detach().numpy().view(np.uint32)
+    out["conv/y_bn"] = y_bn.numpy().view(np.uint32)
+    out["conv/y_ss"] = y_ss.numpy().view(np.uint32)
+    c3, emu = mpt_emu.quantize_model(c2, dtype="e4m3", device="cpu")
+    with torch.no_grad():
+        y_q = c3(x_conv)
+    out["conv/e4m3/w0"] = c3[0].weight.detach().numpy().view(np.uint32)
+    out["conv/e4m3/w3"] = c3[3].weight.detach().numpy().view(np.uint32)
+    out["conv/e4m3/y"] = y_q.numpy().view(np.uint32)
+    np.savez_compressed(os.path.join(HERE, "models.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor"]
+    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor", "models"]
     for w in which:
         globals()["gen_" + w]()
         print("golden:", w, "done")

@@ -71,3 +71,53 @@ def test_module_quant_config_repr():
     m = qutils.ModuleQuantConfig(wt_qconfig=qutils.TensorQuantConfig("e4m3", "rne"))
     assert repr(m).startswith("[weights: [e4m3_rne")
     assert m.device == "cuda" and m.patch_impl == "None"
+
+
+def test_scale_shift_matches_reference_fixture():
+    """BatchNorm2d -> ScaleShift folding against the reference's scale_shift.py output."""
+    import numpy as np
+
+    from _util import npz
+    from mpemu.scale_shift import ScaleShift, replace_batchnorms_with_scaleshifts
+
+    g = npz("models.npz")
+    f = lambda a: torch.from_numpy(a.view(np.float32).copy())
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                            torch.nn.Conv2d(8, 6, 3))
+    m.load_state_dict({k.split("/", 1)[1]: f(g[k]) for k in g.files if k.startswith("conv_init/")}, strict=False)
+    m = replace_batchnorms_with_scaleshifts(m.eval())
+    assert isinstance(m[1], ScaleShift)
+    assert torch.allclose(m[1].weight.detach(), f(g["conv/ss_weight"]), rtol=3e-7, atol=0)
+    assert torch.allclose(m[1].bias.detach(), f(g["conv/ss_bias"]), rtol=1e-6, atol=1e-7)
+    with torch.no_grad():
+        y = m(f(g["x_conv"]))
+    assert torch.allclose(y, f(g["conv/y_bn"]), rtol=1e-4, atol=1e-4)
+
+
+def test_emulator_recipe_tables():
+    """Default TensorQuantConfigs per recipe (reference e5m2_emu.py:55-61, e4m3_emu.py:46-49,176-185,
+    e3m4_emu.py:45-48,159-168, hybrid_emu.py:56-61,400-413)."""
+    from mpemu.e3m4_emu import E3M4Emulator
+    from mpemu.e4m3_emu import E4M3Emulator
+    from mpemu.e5m2_emu import E5M2Emulator
+    from mpemu.hybrid_emu import HybridEmulator
+
+    m = torch.nn.Linear(4, 4)
+    h = HybridEmulator(m, None)
+    assert repr(h.wt_qconfig) == "[e4m3_rne, scale: per-tensor, method: max]"
+    assert repr(h.wtgrad_qconfig) == "[e5m2_stochastic, scale: None, method: max]" and h.emb_qconfig is None
+    h.set_default_inference_qconfig()
+    assert repr(h.wt_qconfig) == "[e3m4_rne, scale: per-channel, method: max]" and h.igrad_qconfig is None
+    e5 = E5M2Emulator(m, None)
+    assert repr(e5.oact_qconfig) == "[e5m2_rne, scale: None, method: max]"
+    e5.set_default_inference_qconfig()
+    assert repr(e5.wt_qconfig) == "[e5m2_rne, scale: per-channel, method: mean]" and e5.oact_qconfig is None
+    e4 = E4M3Emulator(m, None)
+    assert repr(e4.wt_qconfig) == "[e4m3_rne, scale: None, method: max]" and not e4.is_training
+    e4.set_default_inference_qconfig()
+    assert repr(e4.iact_qconfig) == "[e4m3_rne, scale: per-tensor, method: max]"
+    e3 = E3M4Emulator(m, None)
+    assert repr(e3.wt_qconfig) == "[e3m4_rne, scale: per-channel, method: max]"
+    e3.set_calibration_qconfig()
+    assert repr(e3.wt_qconfig) == "[e3m4_rne, scale: per-tensor, method: max]"
+    assert torch.nn.LayerNorm in h.whitelist and torch.nn.LayerNorm not in e4.whitelist
