@@ -80,8 +80,12 @@ def _check(rc):
 def parse_mode(mode):
     """(fmt, rmode) ids of a reference mode string; raises ValueError for an unknown string
     (the reference silently does nothing, cpp/fpemu_impl.cpp:1994-2000)."""
+    hit = _mode_cache.get(mode)
+    if hit is not None:
+        return hit
     f, r = ctypes.c_int(), ctypes.c_int()
     _check(lib().fpemu_parse_mode(str(mode).encode(), ctypes.byref(f), ctypes.byref(r)))
+    _mode_cache[mode] = (f.value, r.value)
     return f.value, r.value
 
 
@@ -100,8 +104,36 @@ def _require_device(t, what="input"):
         raise RuntimeError("fpemu: %s must be contiguous" % what)  # hip/fpemu_impl.cpp:23-25
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    """Raw hipStream_t of torch's current stream on t's device (the launch stream)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _NoCtx(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def _on_device(t):
+    """Context that makes t's device current; free when it already is (the common case)."""
+    if _cur_device is not None and _cur_device() == t.device.index:
+        return _NOCTX
+    return torch.cuda.device_of(t)
+
+
+_mode_cache = {}
 
 
 # ---- stochastic-rounding stream state: (seed, per-call offset) -----------------------------
@@ -141,7 +173,7 @@ def cast_(src, dst, fmt, rmode, scale=1.0, seed=None, offset=None, elem_base=0):
         raise ValueError("fpemu: input/output mismatch")
     if offset is None:
         offset = _next_offset(rmode)
-    with torch.cuda.device_of(src):
+    with _on_device(src):
         _check(lib().fpemu_cast(src.data_ptr(), dst.data_ptr(), src.numel(), _dtype_id(src), fmt, rmode,
                                 float(scale), _seed if seed is None else seed, offset, elem_base,
                                 _stream(src)))
@@ -151,7 +183,7 @@ def cast_(src, dst, fmt, rmode, scale=1.0, seed=None, offset=None, elem_base=0):
 def amax_(src, amax_bits):
     """amax_bits (int32[1], same device, zeroed by the caller) <- max(amax_bits, bits(max|src|))."""
     _require_device(src)
-    with torch.cuda.device_of(src):
+    with _on_device(src):
         _check(lib().fpemu_amax(src.data_ptr(), src.numel(), _dtype_id(src), amax_bits.data_ptr(),
                                 _stream(src)))
     return amax_bits
@@ -163,7 +195,7 @@ def cast_scaled_(src, dst, fmt, rmode, amax_bits, flt_max, clamp=True, seed=None
     _require_device(dst, "output")
     if offset is None:
         offset = _next_offset(rmode)
-    with torch.cuda.device_of(src):
+    with _on_device(src):
         _check(lib().fpemu_cast_scaled(src.data_ptr(), dst.data_ptr(), src.numel(), _dtype_id(src), fmt,
                                        rmode, amax_bits.data_ptr(), float(flt_max), int(bool(clamp)),
                                        _seed if seed is None else seed, offset, elem_base, _stream(src)))
@@ -176,7 +208,7 @@ def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None, clamp=True
     _require_device(dst, "output")
     if amax_ws is None:
         amax_ws = torch.empty(1, dtype=torch.int32, device=src.device)
-    with torch.cuda.device_of(src):
+    with _on_device(src):
         _check(lib().fpemu_quantize_per_tensor(src.data_ptr(), dst.data_ptr(), src.numel(),
                                                _dtype_id(src), fmt, rmode, float(flt_max),
                                                int(bool(clamp)), amax_ws.data_ptr(), _seed, _next_offset(rmode),
@@ -196,7 +228,7 @@ def quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=True):
     off = _offset
     if rmode == STOCHASTIC:
         _offset += rows  # one call offset per row, as a loop of per-row casts would consume
-    with torch.cuda.device_of(src):
+    with _on_device(src):
         _check(lib().fpemu_quantize_rows(src.data_ptr(), dst.data_ptr(), rows, n // rows, _dtype_id(src),
                                          fmt, rmode, float(flt_max), int(bool(clamp)), _seed, off,
                                          _stream(src)))
@@ -211,7 +243,7 @@ def forward(input, mode, size, inplace, scale, block_norm=False, block_size=1):
         raise ValueError("fpemu.forward: size (%d) != input.numel() (%d)" % (size, input.numel()))
     _, rmode = parse_mode(mode)
     out = input if inplace else torch.empty_like(input)
-    with torch.cuda.device_of(input):
+    with _on_device(input):
         _check(lib().fpemu_forward(input.data_ptr(), out.data_ptr(), _dtype_id(input), str(mode).encode(),
                                    input.numel(), float(scale), int(bool(block_norm)), int(block_size),
                                    _seed, _next_offset(rmode), _stream(input)))

@@ -316,3 +316,21 @@ def test_rows_kernel_rejects_scale_free_formats(hip):
         hip.quantize_rows_(t, torch.empty_like(t), 4, fmt, rm, 1.0)
     with pytest.raises(ValueError):
         hip.quantize_rows_(t, torch.empty_like(t), 5, *hip.parse_mode("E4M3_RNE"), 448.0)
+
+
+@pytest.mark.parametrize("mode", ["E4M3_RNE", "E5M2_STOCHASTIC", "E3M4_STOCHASTIC"])
+@pytest.mark.parametrize("n", [1, 1000, 32767, 32768, 32769, 70000])
+def test_fused_per_tensor_small_and_large_paths_agree(hip, mode, n):
+    """<= 32768 elements take the one-workgroup fused path, larger ones amax + cast launches: both
+    must give the oracle's bits (incl. the stochastic noise) and publish the amax word."""
+    fmt, rm = hip.parse_mode(mode)
+    fmax = FLT_MAX[mode.split("_")[0]]
+    x = (np.random.default_rng(n).standard_normal(n) * 3).astype(np.float32)
+    t = torch.from_numpy(x).to(DEV)
+    o = torch.empty_like(t)
+    ws = torch.full((1,), 12345, dtype=torch.int32, device=DEV)
+    hip.set_rng_state((5, 40))
+    hip.quantize_per_tensor_(t, o, fmt, rm, fmax, amax_ws=ws)
+    s = orc.scale_from_amax(orc.amax(x), fmax)
+    assert_bits_equal(o.cpu().numpy(), orc.cast(x, mode, scale=s, seed=5, offset=40), "%s n=%d" % (mode, n))
+    assert ws.view(torch.float32).item() == float(orc.amax(x))
