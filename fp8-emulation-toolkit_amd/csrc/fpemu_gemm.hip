@@ -1,0 +1,336 @@
+// fpemu_gemm.hip -- the cmodel "simple" emulated GEMM for MI355X (gfx950).
+//
+// Replaces the reference's CPU cmodel GEMM
+//   simple_sgemm_impl   mpemu/cmodel/simple/simple_gemm_impl.cpp:71-237
+//   MMEngine_avx2_ps    mpemu/cmodel/simple/simple_mm_engine.cpp:13-27
+//   simple_gemm         mpemu/cmodel/simple/simple_gemm.cpp:45-67
+// whose numerical contract is: every output element is an fp32 chain over k ASCENDING, starting from
+// +0, of the engine's add(c, mul(a, b)); then  C = C + (alpha * acc + beta * C)  with beta = 0
+// (impl.cpp:226-231).  No FP8 rounding happens inside: operands are pre-quantised by the cast kernels.
+// How add(c, mul(a, b)) rounds depends on how the reference is compiled: with its own flags
+// (-march=native, g++ default -ffp-contract=fast) on an FMA host it becomes vfmadd231ps, an fmaf chain;
+// without FMA it is a rounded product then a rounded sum.  Both builds are pinned (tests/golden/gemm.npz).
+//
+// gemm_mfma_kernel   the fmaf chain, on v_mfma_f32_32x32x2_f32 (k-ordered, one rounding per step; bit-
+//                    exact against the reference's FMA build).  128x128x16 tiles, 4 waves, each a 64x64
+//                    quadrant as 2x2 MFMA tiles.  Roofline: fp32 MFMA, 157 TFLOP/s.
+// gemm_seqk_kernel   separate roundings: LDS-tiled VALU kernel, v_mul_f32 + v_add_f32 per step
+//                    (-ffp-contract=off), 8x8 outputs per lane, register prefetch of the next tile,
+//                    XCD-aware tile order.  Bit-exact against the reference's no-FMA build.  Roofline:
+//                    VALU at one multiply + one add per MAC = 78.6 TFLOP/s.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fpemu_hip.h"
+
+extern "C" void fpemu_set_error_(const char *msg);  // fpemu_hip.hip: thread-local error text
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDT = 132;  // LDS row stride in floats (pad 4: 2-way instead of 4-way write conflicts)
+constexpr int NT = 256;
+
+// Operand view: element (r, k) of op(X) with r the M (or N) index.
+//   KCONT = true : memory is [R][K] row-major (k contiguous)   -> A not transposed, B transposed
+//   KCONT = false: memory is [K][R] row-major (r contiguous)   -> A transposed,     B not transposed
+struct Operand {
+  const float *p;
+  int64_t ld;   // leading dimension (elements) of the stored matrix
+  int R, K;     // extents of op(X): R rows (M or N), K depth
+  int vec;      // 16-byte loads allowed (alignment + extents checked on the host)
+};
+
+// Stage one BK x 128 tile (rows r0.., depth k0..) into registers: 2 x float4 per thread.
+template <bool KCONT>
+__device__ __forceinline__ void tile_load(const Operand &X, int r0, int k0, int tid, f32x4 (&v)[2]) {
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    int r, k;
+    if constexpr (KCONT) {  // thread -> (row, 4 consecutive k)
+      r = r0 + h * 64 + (tid >> 2);
+      k = k0 + (tid & 3) * 4;
+    } else {                // thread -> (k, 4 consecutive rows)
+      k = k0 + h * 8 + (tid >> 5);
+      r = r0 + (tid & 31) * 4;
+    }
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (KCONT) {
+      if (r < X.R) {
+        const float *src = X.p + (int64_t)r * X.ld + k;
+        if (X.vec && k + 3 < X.K) {
+          t = *reinterpret_cast<const f32x4 *>(src);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            if (k + c < X.K) t[c] = src[c];
+        }
+      }
+    } else {
+      if (k < X.K) {
+        const float *src = X.p + (int64_t)k * X.ld + r;
+        if (X.vec && r + 3 < X.R) {
+          t = *reinterpret_cast<const f32x4 *>(src);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            if (r + c < X.R) t[c] = src[c];
+        }
+      }
+    }
+    v[h] = t;
+  }
+}
+
+// Registers -> LDS image T[k][r] (k-major, row stride LDT).
+template <bool KCONT>
+__device__ __forceinline__ void tile_store(float *T, int tid, const f32x4 (&v)[2]) {
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    if constexpr (KCONT) {
+      const int r = h * 64 + (tid >> 2), k = (tid & 3) * 4;
+#pragma unroll
+      for (int c = 0; c < 4; c++) T[(k + c) * LDT + r] = v[h][c];
+    } else {
+      const int k = h * 8 + (tid >> 5), r = (tid & 31) * 4;
+      *reinterpret_cast<f32x4 *>(&T[k * LDT + r]) = v[h];
+    }
+  }
+}
+
+// XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch), so give each XCD a
+// contiguous run of tiles, and walk tiles in groups of 8 tile-rows so a run shares A rows / B columns
+// in that XCD's L2.  Bijective for any grid.
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int &tm, int &tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int g = wg / per_group;
+  const int first = g * GROUP;
+  const int rows = (tiles_m - first) < GROUP ? (tiles_m - first) : GROUP;
+  const int in_g = wg % per_group;
+  tm = first + in_g % rows;
+  tn = in_g / rows;
+}
+
+// C = C + (alpha * acc + beta * C), element by element as impl.cpp:226-231 writes it.
+__device__ __forceinline__ float epilogue(float c_in, float acc, float alpha, float beta) {
+  const float t = alpha * acc;
+  const float u = beta * c_in;
+  const float w = t + u;
+  return c_in + w;
+}
+
+template <bool A_KCONT, bool B_KCONT>
+__global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, float *C, int64_t ldc,
+                                                       int c_vec, float alpha, float beta,
+                                                       int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+  const int tid = threadIdx.x;
+  int tm, tn;
+  tile_of_block(tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int ty = tid >> 4, tx = tid & 15;  // lane owns rows {ty*4.., 64+ty*4..} x cols {tx*4.., 64+tx*4..}
+  const int K = A.K;
+
+  float acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[i][j] = 0.f;
+
+  f32x4 pa[2], pb[2];
+  tile_load<A_KCONT>(A, m0, 0, tid, pa);
+  tile_load<B_KCONT>(B, n0, 0, tid, pb);
+  tile_store<A_KCONT>(As[0], tid, pa);
+  tile_store<B_KCONT>(Bs[0], tid, pb);
+  __syncthreads();
+
+  int cur = 0;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool more = k0 + BK < K;
+    if (more) {
+      tile_load<A_KCONT>(A, m0, k0 + BK, tid, pa);
+      tile_load<B_KCONT>(B, n0, k0 + BK, tid, pb);
+    }
+    const float *as = As[cur], *bs = Bs[cur];
+#pragma unroll 2
+    for (int kk = 0; kk < BK; kk++) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&as[kk * LDT + ty * 4]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&as[kk * LDT + 64 + ty * 4]);
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(&bs[kk * LDT + tx * 4]);
+      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(&bs[kk * LDT + 64 + tx * 4]);
+      const float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const float b[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float p = a[i] * b[j];  // rounded product: its own value (contraction is off)
+          acc[i][j] = acc[i][j] + p;    // k ascending, one add per step
+        }
+    }
+    if (more) {
+      tile_store<A_KCONT>(As[cur ^ 1], tid, pa);
+      tile_store<B_KCONT>(Bs[cur ^ 1], tid, pb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const int M = A.R, N = B.R;
+#pragma unroll
+  for (int ih = 0; ih < 2; ih++)
+#pragma unroll
+    for (int ii = 0; ii < 4; ii++) {
+      const int r = m0 + ih * 64 + ty * 4 + ii;
+      if (r >= M) continue;
+#pragma unroll
+      for (int jh = 0; jh < 2; jh++) {
+        const int c = n0 + jh * 64 + tx * 4;
+        float *dst = C + (int64_t)r * ldc + c;
+        if (c_vec && c + 3 < N) {
+          f32x4 ci = *reinterpret_cast<const f32x4 *>(dst), o;
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++) o[jj] = epilogue(ci[jj], acc[ih * 4 + ii][jh * 4 + jj], alpha, beta);
+          *reinterpret_cast<f32x4 *>(dst) = o;
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++)
+            if (c + jj < N) dst[jj] = epilogue(dst[jj], acc[ih * 4 + ii][jh * 4 + jj], alpha, beta);
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA fp32-accumulate variant.  4 waves per block, wave w owns the 64x64 quadrant (w>>1, w&1) of a
+// 128x128 tile as 2x2 MFMA 32x32 tiles.  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5]
+// and B[k = l>>5][j = l&31]; D[reg]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// ---------------------------------------------------------------------------------------------
+template <bool A_KCONT, bool B_KCONT>
+__global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
+                                                       float alpha, float beta, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int tm, tn;
+  tile_of_block(tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int li = lane & 31, lk = lane >> 5;
+  const int K = A.K;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  f32x4 pa[2], pb[2];
+  tile_load<A_KCONT>(A, m0, 0, tid, pa);
+  tile_load<B_KCONT>(B, n0, 0, tid, pb);
+  tile_store<A_KCONT>(As[0], tid, pa);
+  tile_store<B_KCONT>(Bs[0], tid, pb);
+  __syncthreads();
+
+  int cur = 0;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool more = k0 + BK < K;
+    if (more) {
+      tile_load<A_KCONT>(A, m0, k0 + BK, tid, pa);
+      tile_load<B_KCONT>(B, n0, k0 + BK, tid, pb);
+    }
+    const float *as = As[cur], *bs = Bs[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) a[i] = as[(kk + lk) * LDT + wm + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < 2; j++) b[j] = bs[(kk + lk) * LDT + wn + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      tile_store<A_KCONT>(As[cur ^ 1], tid, pa);
+      tile_store<B_KCONT>(Bs[cur ^ 1], tid, pb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const int M = A.R, N = B.R;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int col = n0 + wn + j * 32 + li;
+        if (row < M && col < N) {
+          float *dst = C + (int64_t)row * ldc + col;
+          *dst = epilogue(*dst, acc[i][j][r], alpha, beta);
+        }
+      }
+}
+
+typedef void (*seqk_fn)(Operand, Operand, float *, int64_t, int, float, float, int, int);
+typedef void (*mfma_fn)(Operand, Operand, float *, int64_t, float, float, int, int);
+
+bool aligned16(const void *p) { return ((uintptr_t)p % 16u) == 0; }
+
+}  // namespace
+
+extern "C" int fpemu_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                              int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans,
+                              int b_trans, int variant, void *stream) {
+  auto fail = [](int code, const char *msg) { fpemu_set_error_(msg); return code; };
+  if (M <= 0 || N <= 0) return FPEMU_OK;
+  if (C == nullptr || (K > 0 && (A == nullptr || B == nullptr))) return fail(FPEMU_EINVAL, "fpemu_gemm_f32: null matrix");
+  if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || K < 0)
+    return fail(FPEMU_EINVAL, "fpemu_gemm_f32: dimension out of range");
+  if (((uintptr_t)C % 4u) || ((uintptr_t)A % 4u) || ((uintptr_t)B % 4u))
+    return fail(FPEMU_EALIGN, "fpemu_gemm_f32: matrix not aligned to 4 bytes");
+  // op(A) is M x K: stored [M][K] (k contiguous) or, transposed, [K][M].  op(B) is K x N: stored
+  // [K][N] (n contiguous) or, transposed, [N][K] (k contiguous).   (simple_gemm.cpp:52-65)
+  Operand a, b;
+  a.p = A; a.ld = lda; a.R = (int)M; a.K = (int)K;
+  b.p = B; b.ld = ldb; b.R = (int)N; b.K = (int)K;
+  const bool a_kcont = !a_trans, b_kcont = b_trans != 0;
+  a.vec = aligned16(A) && (lda % 4 == 0) && ((a_kcont ? K : M) % 4 == 0);
+  b.vec = aligned16(B) && (ldb % 4 == 0) && ((b_kcont ? K : N) % 4 == 0);
+  const int c_vec = aligned16(C) && (ldc % 4 == 0) && (N % 4 == 0);
+  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+  const int64_t nwg = (int64_t)tiles_m * tiles_n;
+  if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "fpemu_gemm_f32: too many tiles");
+  const float beta = 0.0f;  // simple_gemm.cpp:58
+  hipStream_t s = (hipStream_t)stream;
+  if (variant == 0) {
+    seqk_fn fn = a_kcont ? (b_kcont ? gemm_seqk_kernel<true, true> : gemm_seqk_kernel<true, false>)
+                         : (b_kcont ? gemm_seqk_kernel<false, true> : gemm_seqk_kernel<false, false>);
+    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(NT), 0, s, a, b, C, ldc, c_vec, alpha, beta, tiles_m,
+                       tiles_n);
+  } else if (variant == 1) {
+    mfma_fn fn = a_kcont ? (b_kcont ? gemm_mfma_kernel<true, true> : gemm_mfma_kernel<true, false>)
+                         : (b_kcont ? gemm_mfma_kernel<false, true> : gemm_mfma_kernel<false, false>);
+    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(NT), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n);
+  } else {
+    return fail(FPEMU_EINVAL, "fpemu_gemm_f32: unknown variant");
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FPEMU_OK : fail((int)e, hipGetErrorString(e));
+}

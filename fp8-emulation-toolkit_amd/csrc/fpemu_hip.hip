@@ -429,6 +429,9 @@ extern "C" {
 
 int fpemu_abi_version(void) { return FPEMU_ABI_VERSION; }
 
+// internal (not in the public header): lets the other translation units set the error text
+void fpemu_set_error_(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+
 const char *fpemu_last_error(void) { return g_err; }
 
 void fpemu_set_max_blocks(int mb) { g_max_blocks = mb; }

@@ -1,0 +1,153 @@
+"""mpemu.cmodel.simple -- the "simple" hardware c-model GEMM ops, MI355X build.
+
+Mirror of the reference's mpemu/cmodel/simple.py for the matrix products: `addmm`, `matmul`, `mm`
+with the same signatures and fallbacks, backed by the gfx950 kernels of csrc/fpemu_gemm.hip instead of
+the CPU extension simple_gemm_dev.  Every output element is a k-ascending fp32 accumulation chain
+(no FP8 rounding inside: operands are pre-quantised by the hooks).
+
+Accumulation flavour.  Built with its own flags on an FMA-capable x86 host the reference contracts the
+engine's add(c, mul(a, b)) into vfmadd231ps, i.e. an fmaf chain; on a host without FMA the same source
+rounds the product and the sum separately (oracle/build_ref.py builds both; tests pin both).
+`set_accumulation("fma")` (default, = the reference as built here; runs on the fp32 MFMA, which is
+bit-for-bit that chain) or `set_accumulation("separate")` (explicit per-step rounding, VALU kernel).
+
+Not in this build: conv2d (reference simple_conv2d_*) -- raises.
+Divergence: backward zero-initialises the gradient buffers (the reference accumulates into
+torch.empty_like, simple.py:163-164).
+"""
+import warnings
+
+import torch
+from torch.autograd import Function
+
+from ..pytquant.hip import _binding as _hip
+
+fallback_addmm = torch.addmm
+fallback_matmul = torch.matmul
+fallback_mm = torch.mm
+
+_variant = _hip.GEMM_FMA
+
+
+def set_accumulation(kind):
+    """'fma': fmaf chain (reference on FMA hosts; MFMA kernel).  'separate': multiply and add rounded
+    separately (reference on hosts without FMA; VALU kernel)."""
+    global _variant
+    _variant = {"fma": _hip.GEMM_FMA, "separate": _hip.GEMM_SEPARATE}[kind]
+
+
+def get_accumulation():
+    return "fma" if _variant == _hip.GEMM_FMA else "separate"
+
+
+def is_transposed(input):
+    if input.is_contiguous():
+        return input, False
+    if input.t().is_contiguous():
+        return input.t(), True
+    return input.contiguous(), False
+
+
+def _out_shape(a_mat, a_trans, b_mat, b_trans):
+    return [a_mat.size(1) if a_trans else a_mat.size(0), b_mat.size(0) if b_trans else b_mat.size(1)]
+
+
+def _gemm(out, a, b, alpha, a_trans, b_trans):
+    return _hip.gemm_(out, a, b, alpha, a_trans, b_trans, _variant)
+
+
+def _supported(*ts):
+    return all(t.dtype == torch.float32 and t.is_cuda for t in ts)
+
+
+def addmm(input, mat1, mat2, beta=1.0, alpha=1.0, out=None):
+    if _supported(input, mat1, mat2) and mat1.dim() == 2 and mat2.dim() == 2 and mat1.size(1) == mat2.size(0):
+        a_mat, a_trans = is_transposed(mat1)
+        b_mat, b_trans = is_transposed(mat2)
+        output = out if out is not None else torch.zeros(_out_shape(a_mat, a_trans, b_mat, b_trans),
+                                                         device=mat1.device)
+        return SimpleAddmm.apply(output, input, a_mat, b_mat, alpha, beta, a_trans, b_trans)
+    warnings.warn('simple.addmm does not support the input dimensions - input :{}, mat1: {}, mat2: {}, '
+                  'falling back to torch.addmm'.format(input.size(), mat1.size(), mat2.size()))
+    return fallback_addmm(input, mat1, mat2, beta=beta, alpha=alpha, out=out)
+
+
+def matmul(input, other, out=None):
+    if _supported(input, other) and input.dim() == 2 and other.dim() == 2 and input.size(1) == other.size(0):
+        return mm(input, other, out=out)
+    if _supported(input, other) and input.dim() == 3 and other.dim() == 2 and input.size(2) == other.size(0):
+        b_mat, b_trans = is_transposed(other)
+        n = b_mat.size(0) if b_trans else b_mat.size(1)
+        outs = out if out is not None else torch.zeros([input.size(0), input.size(1), n], device=input.device)
+        res = []
+        for i in range(input.size(0)):
+            a_mat, a_trans = is_transposed(input[i])
+            res.append(SimpleMatmul.apply(outs[i], a_mat, b_mat, 1.0, a_trans, b_trans))
+        return torch.stack(res)
+    warnings.warn('simple.matmul does not support the input dimensions - input :{}, other: {}, falling back '
+                  'to torch.matmul'.format(input.size(), other.size()))
+    return fallback_matmul(input, other, out=out)
+
+
+def mm(input, mat2, out=None):
+    if _supported(input, mat2) and input.dim() == 2 and mat2.dim() == 2 and input.size(1) == mat2.size(0):
+        a_mat, a_trans = is_transposed(input)
+        b_mat, b_trans = is_transposed(mat2)
+        output = out if out is not None else torch.zeros(_out_shape(a_mat, a_trans, b_mat, b_trans),
+                                                         device=input.device)
+        return SimpleMatmul.apply(output, a_mat, b_mat, 1.0, a_trans, b_trans)
+    warnings.warn('simple.mm does not support the input dimensions - input :{}, mat2: {}, falling back to '
+                  'torch.mm'.format(input.size(), mat2.size()))
+    return fallback_mm(input, mat2, out=out)
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    raise NotImplementedError("mpemu (MI355X build): the cmodel direct convolution is not implemented")
+
+
+def _grads(grad_output, mat1, mat2, alpha, a_trans, b_trans):
+    """d/d(mat1), d/d(mat2) of alpha * op(mat1) @ op(mat2), each one cmodel GEMM (simple.py:155-178)."""
+    g1, g2 = torch.zeros_like(mat1), torch.zeros_like(mat2)
+    go, o_trans = is_transposed(grad_output)
+    if a_trans:
+        _gemm(g1, mat2, go, alpha, b_trans, not o_trans)
+    else:
+        _gemm(g1, go, mat2, alpha, o_trans, not b_trans)
+    if b_trans:
+        _gemm(g2, go, mat1, alpha, not o_trans, a_trans)
+    else:
+        _gemm(g2, mat1, go, alpha, not a_trans, o_trans)
+    return g1, g2
+
+
+class SimpleAddmm(Function):
+    @staticmethod
+    def forward(ctx, output, input, mat1, mat2, alpha, beta, a_trans, b_trans):
+        ctx.save_for_backward(mat1, mat2)
+        ctx.a_trans, ctx.b_trans, ctx.alpha = a_trans, b_trans, alpha
+        _gemm(output, mat1, mat2, alpha, a_trans, b_trans)
+        output += beta * input
+        ctx.mark_dirty(output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        mat1, mat2 = ctx.saved_tensors
+        g1, g2 = _grads(grad_output, mat1, mat2, ctx.alpha, ctx.a_trans, ctx.b_trans)
+        return grad_output, grad_output, g1, g2, None, None, None, None
+
+
+class SimpleMatmul(Function):
+    @staticmethod
+    def forward(ctx, output, mat1, mat2, alpha, a_trans, b_trans):
+        ctx.save_for_backward(mat1, mat2)
+        ctx.a_trans, ctx.b_trans, ctx.alpha = a_trans, b_trans, alpha
+        _gemm(output, mat1, mat2, alpha, a_trans, b_trans)
+        ctx.mark_dirty(output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        mat1, mat2 = ctx.saved_tensors
+        g1, g2 = _grads(grad_output, mat1, mat2, ctx.alpha, ctx.a_trans, ctx.b_trans)
+        return grad_output, g1, g2, None, None, None

@@ -60,6 +60,9 @@ def lib():
         L.fpemu_quantize_per_tensor.argtypes = [vp, vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, vp]
         L.fpemu_quantize_rows.restype = i32
         L.fpemu_quantize_rows.argtypes = [vp, vp, u64, u64, i32, i32, i32, f32, i32, u64, u64, vp]
+        i64 = ctypes.c_int64
+        L.fpemu_gemm_f32.restype = i32
+        L.fpemu_gemm_f32.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, i32, i32, i32, vp]
         L.fpemu_set_max_blocks.restype = None
         L.fpemu_set_max_blocks.argtypes = [i32]
         if L.fpemu_abi_version() != 1:
@@ -233,6 +236,32 @@ def quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=True):
                                          fmt, rmode, float(flt_max), int(bool(clamp)), _seed, off,
                                          _stream(src)))
     return dst
+
+
+GEMM_SEPARATE, GEMM_FMA = 0, 1
+
+
+def gemm_(C, A, B, alpha=1.0, a_trans=False, b_trans=False, variant=GEMM_FMA):
+    """C += alpha * op(A) @ op(B) with the cmodel's k-ascending fp32 accumulation chain; the call
+    simple_gemm_dev.gemm(C, A, B, alpha, a_trans, b_trans) of the reference
+    (mpemu/cmodel/simple/simple_gemm.cpp:45-67).  A is stored [K, M] when a_trans, B [N, K] when
+    b_trans.  variant: GEMM_FMA (fmaf chain on MFMA) or GEMM_SEPARATE (multiply and add rounded
+    separately, VALU)."""
+    for t, what in ((C, "C"), (A, "A"), (B, "B")):
+        _require_device(t, what)
+        if t.dtype != torch.float32 or t.dim() != 2:
+            raise TypeError("fpemu gemm: %s must be a 2-D float32 tensor" % what)
+    M, N = C.shape
+    K = A.shape[0] if a_trans else A.shape[1]
+    if (A.shape[1] if a_trans else A.shape[0]) != M or (B.shape[0] if b_trans else B.shape[1]) != N or \
+            (B.shape[1] if b_trans else B.shape[0]) != K:
+        raise ValueError("fpemu gemm: shapes do not match: C %s, A %s (trans=%s), B %s (trans=%s)" % (
+            tuple(C.shape), tuple(A.shape), a_trans, tuple(B.shape), b_trans))
+    with _on_device(C):
+        _check(lib().fpemu_gemm_f32(C.data_ptr(), A.data_ptr(), B.data_ptr(), M, N, K, A.shape[1], B.shape[1],
+                                    C.shape[1], float(alpha), int(bool(a_trans)), int(bool(b_trans)),
+                                    int(variant), _stream(C)))
+    return C
 
 
 def forward(input, mode, size, inplace, scale, block_norm=False, block_size=1):

@@ -132,6 +132,25 @@ int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols,
                         int rmode, float flt_max, int clamp, uint64_t seed, uint64_t offset,
                         void *stream);
 
+/* cmodel emulated GEMM ("next" row of the hot path; BASELINE config 5).  Replaces the reference's CPU
+ * cmodel entry point  simple_gemm_dev.gemm(C, A, B, alpha, a_trans, b_trans)
+ * (mpemu/cmodel/simple/simple_gemm.cpp:45-67 -> simple_sgemm_impl, simple_gemm_impl.cpp:71-237 ->
+ * MMEngine_avx2_ps, simple_mm_engine.cpp:13-27).  Row-major fp32 matrices:
+ *   C is M x N (ldc);  op(A) is M x K: A stored [M][K], or [K][M] when a_trans;  op(B) is K x N: B stored
+ *   [K][N], or [N][K] when b_trans;  lda / ldb are the stored matrices' row strides in elements.
+ *   C[i][j] = C[i][j] + (alpha * acc_ij + 0 * C[i][j]),   acc_ij = chain over k ascending from +0
+ * variant 1 (FPEMU_GEMM_FMA, the drop-in default): acc = fmaf(a, b, acc) per step, on
+ *            v_mfma_f32_32x32x2_f32.  This is the reference as its own setup.py builds it on an FMA-capable
+ *            x86 host (-march=native, g++'s default -ffp-contract=fast contracts the engine's
+ *            _mm256_add_ps(c, _mm256_mul_ps(a, b)), simple_mm_engine.cpp:13-27, into vfmadd231ps).
+ * variant 0 (FPEMU_GEMM_SEPARATE): acc = fp32(acc + fp32(a*b)) per step, VALU, LDS-tiled: the same source
+ *            compiled for a host without FMA (separate vmulps / vaddps).
+ * Both are bit-identical to the corresponding reference build (tests/golden/gemm.npz holds both).
+ * C accumulates into its existing contents exactly as the reference does: pass zeros for a plain product. */
+int fpemu_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                   int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans,
+                   int variant, void *stream);
+
 /* Launch-geometry override for benchmarking sweeps: blocks per launch cap (0 = default).
  * Affects performance only, never results. */
 void fpemu_set_max_blocks(int max_blocks);

@@ -73,14 +73,21 @@ def load(variant, verbose=False):
     )
 
 
-def load_cmodel(which, verbose=False):
-    """which: 'simple_gemm_dev' | 'simple_conv2d_dev' (module names the reference imports)."""
+def load_cmodel(which, verbose=False, nofma=False):
+    """which: 'simple_gemm_dev' | 'simple_conv2d_dev' (module names the reference imports).
+
+    With the reference's own flags (-march=native; g++ defaults to -ffp-contract=fast) GCC contracts
+    the engine's _mm256_add_ps(c, _mm256_mul_ps(a, b)) into vfmadd231ps on an FMA host: the accumulation
+    is an fmaf chain.  nofma=True adds -mno-fma -mno-avx512f (AVX-512F carries its own EVEX fused
+    multiply-add): the same sources as a host without FMA compiles them, i.e. separate vmulps / vaddps
+    roundings.  Both are "the reference"; DESIGN.md says which kernel variant pins which."""
     srcs = {
         "simple_gemm_dev": ["simple_gemm.cpp", "simple_gemm_impl.cpp", "simple_mm_engine.cpp"],
         "simple_conv2d_dev": ["simple_conv2d.cpp", "simple_conv2d_impl.cpp", "simple_mm_engine.cpp"],
     }[which]
-    return _load(which, [os.path.join(REF_CMODEL, s) for s in srcs], _CMODEL_FLAGS,
-                 include=[REF_CMODEL], verbose=verbose)
+    name = which + ("_nofma" if nofma else "")
+    flags = _CMODEL_FLAGS + (["-mno-fma", "-mno-avx512f"] if nofma else [])
+    return _load(name, [os.path.join(REF_CMODEL, s) for s in srcs], flags, include=[REF_CMODEL], verbose=verbose)
 
 
 def import_reference_package(variant="native"):
@@ -113,6 +120,8 @@ def main():
     for which in ("simple_gemm_dev", "simple_conv2d_dev"):
         m = load_cmodel(which, verbose=v)
         print("oracle/_ref/%s: built %s" % (which, m.__file__))
+    m = load_cmodel("simple_gemm_dev", verbose=v, nofma=True)
+    print("oracle/_ref/simple_gemm_dev_nofma: built %s" % m.__file__)
     return 0
 
 

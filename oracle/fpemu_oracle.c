@@ -14,6 +14,7 @@
  */
 #include "fpemu_oracle.h"
 
+#include <math.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -420,4 +421,39 @@ int orc_num_threads(void) {
 #else
   return 1;
 #endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cmodel emulated GEMM: simple_sgemm_impl (mpemu/cmodel/simple/simple_gemm_impl.cpp:71-237) with
+ * MMEngine_avx2_ps (simple_mm_engine.cpp:13-27), called as simple_gemm does (simple_gemm.cpp:45-67,
+ * beta = 0).  Per output element: acc = +0; for k ascending: acc = fp32(acc + fp32(a*b)) -- separate
+ * vmulps / vaddps, no FMA -- then C += alpha*acc + beta*C (impl.cpp:226-231).  The reference's
+ * zero padding of K to a multiple of 64 adds +0 to a chain that is never -0: a no-op.
+ * fused != 0 models the MFMA fp32-accumulate variant instead: acc = fmaf(a, b, acc).
+ * Row-major; op(A) = A[M][K] or, a_trans, A[K][M]; op(B) = B[K][N] or, b_trans, B[N][K].
+ * ---------------------------------------------------------------------------------------- */
+void orc_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                  int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans,
+                  int fused) {
+  const float beta = 0.0f;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < M; i++) {
+    for (int64_t j = 0; j < N; j++) {
+      float acc = 0.0f;
+      for (int64_t k = 0; k < K; k++) {
+        const float a = a_trans ? A[k * lda + i] : A[i * lda + k];
+        const float b = b_trans ? B[j * ldb + k] : B[k * ldb + j];
+        if (fused) {
+          acc = fmaf(a, b, acc);
+        } else {
+          volatile float p = a * b;
+          acc = acc + p;
+        }
+      }
+      volatile float t = alpha * acc;
+      volatile float u = beta * C[i * ldc + j];
+      volatile float w = t + u;
+      C[i * ldc + j] = C[i * ldc + j] + w;
+    }
+  }
 }

@@ -60,6 +60,9 @@ def lib():
     L.orc_build_lut.argtypes = [i32, i32, vp]
     L.orc_parse_mode.restype = i32
     L.orc_parse_mode.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    i64 = ctypes.c_int64
+    L.orc_gemm_f32.restype = None
+    L.orc_gemm_f32.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, i32, i32, i32]
     L.orc_num_threads.restype = i32
     L.orc_num_threads.argtypes = []
     _lib = L
@@ -127,6 +130,19 @@ def philox(key, ctr):
 def rand_bits(seed, offset, idx, mode):
     fmt, _ = parse_mode(mode)
     return lib().orc_rand_bits(seed, offset, idx, fmt)
+
+
+def gemm(a, b, alpha=1.0, a_trans=False, b_trans=False, out=None, fused=False):
+    """Oracle of simple_gemm_dev.gemm(C, A, B, alpha, a_trans, b_trans): a, b are the STORED matrices
+    (A is [K, M] when a_trans, B is [N, K] when b_trans); returns C (accumulated into `out` if given)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    M, K = (a.shape[1], a.shape[0]) if a_trans else a.shape
+    N = b.shape[0] if b_trans else b.shape[1]
+    c = np.zeros((M, N), dtype=np.float32) if out is None else out
+    lib().orc_gemm_f32(_ptr(c), _ptr(a), _ptr(b), M, N, K, a.shape[1], b.shape[1], c.shape[1],
+                       np.float32(alpha), int(a_trans), int(b_trans), int(fused))
+    return c
 
 
 def num_threads():

@@ -17,6 +17,7 @@ Fixtures (all loadable with numpy.load(allow_pickle=False) / json):
   sr_hist.json    scalar-reference stochastic-rounding round-up counts (distribution pin)
   qtensor.npz     reference qutils.quantize_tensor (per-tensor / per-channel / fine-grained / mean)
   models.npz      reference mpt_emu.quantize_model / scale_shift on tiny seeded models
+  gemm.npz        reference cmodel simple_gemm_dev.gemm, FMA build and -mno-fma build
 """
 import json
 import os
@@ -209,6 +210,38 @@ def gen_qtensor():
     np.savez_compressed(os.path.join(HERE, "qtensor.npz"), **out)
 
 
+def gen_gemm():
+    """Reference cmodel GEMM (simple_gemm_dev.gemm) from both builds: "fma" = the reference's own flags
+    on this FMA host (vfmadd231ps chain), "nofma" = -mno-fma -mno-avx512f (separate multiply and add)."""
+    builds = {"fma": build_ref.load_cmodel("simple_gemm_dev"),
+              "nofma": build_ref.load_cmodel("simple_gemm_dev", nofma=True)}
+    rng = np.random.default_rng(4242)
+    out = {}
+    names = []
+    for (M, N, K) in [(16, 16, 64), (33, 17, 70), (96, 80, 200), (70, 133, 100), (5, 3, 1), (32, 48, 1024)]:
+        for at in (False, True):
+            for bt in (False, True):
+                if (M * N > 9000 or K > 512) and at != bt:
+                    continue
+                A = (rng.standard_normal((K, M) if at else (M, K)) * np.exp(rng.standard_normal() * 2)).astype(np.float32)
+                B = rng.standard_normal((N, K) if bt else (K, N)).astype(np.float32)
+                key = "%d_%d_%d_%d_%d" % (M, N, K, int(at), int(bt))
+                out["A/" + key] = A.view(np.uint32)
+                out["B/" + key] = B.view(np.uint32)
+                names.append(key)
+                for bname, g in builds.items():
+                    for alpha in (1.0, 1.5):
+                        C = torch.zeros(M, N)
+                        g.gemm(C, torch.from_numpy(A.copy()), torch.from_numpy(B.copy()), alpha, at, bt)
+                        out["C/%s/%s/%g" % (bname, key, alpha)] = C.numpy().view(np.uint32)
+                    # accumulate into a non-zero output: C += alpha*acc + 0*C (simple_gemm_impl.cpp:226-231)
+                    C = torch.from_numpy(np.arange(M * N, dtype=np.float32).reshape(M, N) * 0.25 - 3.0)
+                    g.gemm(C, torch.from_numpy(A.copy()), torch.from_numpy(B.copy()), 0.75, at, bt)
+                    out["Cacc/%s/%s" % (bname, key)] = C.numpy().view(np.uint32)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "gemm.npz"), **out)
+
+
 def _tiny_models():
     torch.manual_seed(1234)
     mlp = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.ReLU(), torch.nn.Linear(64, 24))
@@ -280,7 +313,7 @@ def gen_models():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor", "models"]
+    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor", "models", "gemm"]
     for w in which:
         globals()["gen_" + w]()
         print("golden:", w, "done")

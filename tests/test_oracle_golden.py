@@ -227,3 +227,23 @@ def test_scale_rule_edges():
     x = np.array([1.0, float("nan"), -3.0], dtype=np.float32)
     assert math.isnan(float(orc.amax(x)))
     assert float(orc.amax(np.array([1.0, -7.5, 3.0], dtype=np.float32))) == 7.5
+
+
+@pytest.mark.parametrize("build,fused", [("fma", True), ("nofma", False)])
+def test_gemm_oracle_matches_reference_builds(build, fused):
+    """orc_gemm_f32 vs the reference's simple_gemm_dev.gemm, both ways the reference compiles
+    (oracle/build_ref.py load_cmodel: its own flags contract to FMA; -mno-fma -mno-avx512f does not)."""
+    g = npz("gemm.npz")
+    n = 0
+    for key in g["names"]:
+        key = str(key)
+        M, N, K, at, bt = map(int, key.split("_"))
+        A, B = g["A/" + key].view(np.float32), g["B/" + key].view(np.float32)
+        for alpha in (1.0, 1.5):
+            got = orc.gemm(A, B, alpha, bool(at), bool(bt), fused=fused)
+            assert_bits_equal(got, g["C/%s/%s/%g" % (build, key, alpha)], "%s %s %g" % (build, key, alpha))
+            n += 1
+        c0 = np.arange(M * N, dtype=np.float32).reshape(M, N) * np.float32(0.25) - np.float32(3.0)
+        got = orc.gemm(A, B, 0.75, bool(at), bool(bt), out=c0.copy(), fused=fused)
+        assert_bits_equal(got, g["Cacc/%s/%s" % (build, key)], "%s %s acc" % (build, key))
+    assert n >= 40
