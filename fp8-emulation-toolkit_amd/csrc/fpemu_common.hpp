@@ -1,0 +1,74 @@
+// fpemu_common.hpp -- pieces shared by the kernel translation units (fpemu_hip.hip, fpemu_rows.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fpemu_hip.h"
+#include "fpemu_device.hpp"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace fpemu {
+
+constexpr int kBlock = 256;         // 4 wavefronts
+constexpr int kWavesPerBlock = 4;
+
+template <int DT> struct Storage;
+template <> struct Storage<FPEMU_F32> { static constexpr unsigned V = 4; using elem = float; };
+template <> struct Storage<FPEMU_F16> { static constexpr unsigned V = 8; using elem = uint16_t; };
+template <> struct Storage<FPEMU_BF16> { static constexpr unsigned V = 8; using elem = uint16_t; };
+
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  uint32_t u = f2u(f);
+  const uint32_t rn = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+  const uint32_t nan = (u >> 16) | 0x0040u;
+  return ((u & 0x7FFFFFFFu) > 0x7F800000u) ? nan : rn;
+}
+
+// Streaming 16-byte store with the "sc1 nt" policy bits (write-through, non-temporal): measured
+// +2 % over a plain nt store on MI355X for this read-once / write-once stream (tools/sweep.hip);
+// the builtin only offers "nt".  Vector store only; nothing in the launch reads it back.
+// The trailing s_nop 1 is required: hipcc pads no hazards inside an asm statement, and a VALU
+// write to the data registers right after a >64-bit store would overtake the store's read of them.
+__device__ __forceinline__ void store_stream(u32x4 *p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
+template <int DT> __device__ __forceinline__ float load_elem16(uint32_t b) {
+  if constexpr (DT == FPEMU_F16) return h_to_f32(b);
+  else return u2f(b << 16);
+}
+template <int DT> __device__ __forceinline__ uint32_t store_elem16(float f) {
+  if constexpr (DT == FPEMU_F16) return f32_to_h(f);
+  else return f32_to_bf16_bits(f);
+}
+
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t m) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64);
+    m = m > o ? m : o;
+  }
+  return m;
+}
+
+template <int DT> __device__ __forceinline__ uint32_t absmax_word(uint32_t m, uint32_t w) {
+  if constexpr (DT == FPEMU_F32) {
+    const uint32_t a = w & 0x7FFFFFFFu;
+    return m > a ? m : a;
+  } else {
+    const uint32_t a = w & 0x7FFFu, b = (w >> 16) & 0x7FFFu;
+    const uint32_t c = a > b ? a : b;
+    return m > c ? m : c;
+  }
+}
+
+inline unsigned elem_size(int dtype) { return dtype == FPEMU_F32 ? 4u : 2u; }
+inline unsigned vec_elems(int dtype) { return dtype == FPEMU_F32 ? 4u : 8u; }
+
+}  // namespace fpemu
+
+// thread-local error text of the library (fpemu_hip.hip); returns `code`
+extern "C" void fpemu_set_error_(const char *msg);

@@ -8,6 +8,8 @@
 //   cvt_fp32_e3m4_scalar  mpemu/pytquant/cpp/fpemu_impl.cpp:1624-1718
 //   E5M2_DAZ_Kernel       mpemu/pytquant/cpp/fpemu_impl.cpp:846-919
 //   BFLOAT16 (RNE :207-232 canonical, SR :302-318), FLOAT16_Kernel :356-423
+//   E4M3_IEEE: the AVX-512 routines :1213-1328 (canonical: the scalar one saturates from 15.0, :1364)
+//   FP4_NEAREST: cvt_fp32_fp4_nearest_scalar :1797-1824
 // restated as integer arithmetic on the whole 15-bit magnitude (exponent and mantissa are
 // contiguous, so the reference's "mantissa += inc; mantissa + (exp << 10)" carry is a plain add).
 #pragma once
@@ -17,7 +19,8 @@
 
 namespace fpemu {
 
-enum Fmt : int { E5M2 = 0, E4M3 = 1, E3M4 = 2, BF16 = 3, FP16 = 4, E5M2_DAZ = 5, FP16_DAZ = 6 };
+enum Fmt : int { E5M2 = 0, E4M3 = 1, E3M4 = 2, BF16 = 3, FP16 = 4, E5M2_DAZ = 5, FP16_DAZ = 6,
+                 E4M3_IEEE = 7, FP4 = 8 };
 enum RMode : int { RTZ = 0, RNE = 1, STOCHASTIC = 2, RNAZ = 3, RNTZ = 4, RPINF = 5, RNINF = 6 };
 
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
@@ -80,7 +83,8 @@ __device__ __forceinline__ uint32_t quant_e5m2(uint32_t h, uint32_t rnd) {
 //   SAT    magnitude of the largest value as fp16 bits (0x5F00 = 448 / 0x4F80 = 30)
 //   FLUSH  smallest magnitude kept (0x1800 = 2^-9 / 0x2400 = 2^-6); below: +-0
 //   ENORM  fp16 exponent field of the smallest normal (9 = 2^-6 / 13 = 2^-2)
-template <int RM, int K, uint32_t SAT, uint32_t FLUSH, int ENORM>
+//   SUB_RNE  under STOCHASTIC the pseudo-subnormal range rounds RNE (E4M3_IEEE, cpp:1312-1315)
+template <int RM, int K, uint32_t SAT, uint32_t FLUSH, int ENORM, bool SUB_RNE = false>
 __device__ __forceinline__ uint32_t quant_e4m3_e3m4(uint32_t h, uint32_t rnd) {
   const uint32_t a = h & 0x7FFFu;
   const uint32_t sgn = h & 0x8000u;
@@ -92,6 +96,10 @@ __device__ __forceinline__ uint32_t quant_e4m3_e3m4(uint32_t h, uint32_t rnd) {
   uint32_t r;
   if constexpr (RM == STOCHASTIC) {
     r = m + (rnd & ((1u << K) - 1u));  // every non-flushed value is an fp16 normal (cpp:1106)
+    if constexpr (SUB_RNE) {
+      const uint32_t ne = m + (round_inc<RNE, K>(m, neg, a != 0u) << K);
+      r = ((int)(a >> 10) < ENORM) ? ne : r;
+    }
   } else {
     r = m + (round_inc<RM, K>(m, neg, a != 0u) << K);
   }
@@ -107,6 +115,7 @@ __device__ __forceinline__ uint32_t quant_h(uint32_t h, uint32_t rnd) {
   else if constexpr (FMT == E5M2_DAZ) return quant_e5m2<RM, true>(h, rnd);
   else if constexpr (FMT == E4M3) return quant_e4m3_e3m4<RM, 7, 0x5F00u, 0x1800u, 9>(h, rnd);
   else if constexpr (FMT == E3M4) return quant_e4m3_e3m4<RM, 6, 0x4F80u, 0x2400u, 13>(h, rnd);
+  else if constexpr (FMT == E4M3_IEEE) return quant_e4m3_e3m4<RM, 7, 0x5B80u, 0x1800u, 9, true>(h, rnd);
   else return h;
 }
 
@@ -143,6 +152,27 @@ __device__ __forceinline__ float cast_fp16(float x, uint32_t rnd) {
   return h_to_f32(h);
 }
 
+// FP4_NEAREST on the fp32 pattern (cpp:1797-1824): outputs are the even powers of two 2^0 .. 2^-12 and 0.
+__device__ __forceinline__ float cast_fp4(float x, float scale, float rcp) {
+  float p = x * scale;
+  asm volatile("" : "+v"(p));
+  uint32_t u = f2u(p);
+  const uint32_t sgn = u & 0x80000000u;
+  const int e0 = (int)((u >> 23) & 0xFFu) - 127;
+  const bool odd0 = (e0 < 0) && (e0 & 1);
+  // "see if round up works": x * 1.6 as a double product rounded back to fp32 (cpp:1811)
+  const float up = (float)((double)p * 1.6);
+  u = odd0 ? f2u(up) : u;
+  u = (e0 > 0) ? (sgn | 0x3F800000u) : u;   // exponent > 0, Inf and NaN: +-1.0
+  u &= 0xFF800000u;
+  const int e1 = (int)((u >> 23) & 0xFFu) - 127;
+  u = ((e1 < 0) && (e1 & 1)) ? (sgn | ((uint32_t)(e1 + 126) << 23)) : u;  // still odd: one exponent down
+  u = (e1 < -12) ? 0u : u;                  // below 2^-12: +0
+  float r = u2f(u) * rcp;
+  asm volatile("" : "+v"(r));
+  return r;
+}
+
 // One element, fp32 in -> fp32 out.  scale / rcp are ignored by BF16 and FP16 (the reference's
 // BFLOAT16_Kernel / FLOAT16_Kernel take no scale, cpp:1933-1957).
 template <int FMT, int RM>
@@ -153,6 +183,8 @@ __device__ __forceinline__ float cast_one(float x, float scale, float rcp, uint3
     return cast_fp16<RM, false>(x, rnd);
   } else if constexpr (FMT == FP16_DAZ) {
     return cast_fp16<RM, true>(x, rnd);
+  } else if constexpr (FMT == FP4) {
+    return cast_fp4(x, scale, rcp);
   } else {
     float p = x * scale;
     // Keep the fp32 product a value of its own: two roundings (fp32, then fp16) are the
@@ -226,6 +258,19 @@ __device__ __forceinline__ float scale_from_amax(uint32_t amax_bits, float flt_m
   float s = r * flt_max;
   if (clamp && s > 3.275e4f) s = 6.55e4f;
   return s;
+}
+
+// Block-norm scale from the block's max |x| (cpp:794-799, :1166-1171, :1458-1463, :1751-1755, :1858).
+template <int FMT>
+__device__ __forceinline__ float blocknorm_scale(uint32_t amax_bits) {
+  if constexpr (FMT == FP4) {
+    return (float)(1.0 / (double)u2f(amax_bits));
+  } else {
+    float s = 2.0f * u2f(amax_bits & 0x7F800000u);
+    if constexpr (FMT == E5M2) s = s / 16384.0f;
+    else if constexpr (FMT == E4M3 || FMT == E4M3_IEEE) s = s / 8.0f;
+    return s;
+  }
 }
 
 // (float)(1.0 / (double)scale), cpp:714 / :1060 / :1646.

@@ -22,20 +22,21 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "../../include/fpemu_hip.h"
-#include "fpemu_device.hpp"
+#include "fpemu_common.hpp"
 
 using namespace fpemu;
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// fpemu_rows.hip: one launch of the per-row (per-channel / per-block) kernel
+extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype,
+                                  int fmt, int rmode, float flt_max, int policy, uint64_t seed,
+                                  uint64_t offset, uint32_t *amax_out, int force_block, void *stream);
 
 namespace {
 
-constexpr int kBlock = 256;         // 4 wavefronts
-constexpr int kWavesPerBlock = 4;
 constexpr int kDefaultMaxBlocks = 0x7FFFFFFF;  // cast: one superblock per wave, no loop
 constexpr int kAmaxMaxBlocks = 256 * 16;       // amax: looped, one atomic per block
 constexpr uint64_t kSmallTensor = 32768;       // <= this many elements: fused one-workgroup path
+constexpr int kNoRowsKernel = -100;            // fpemu_rows_launch_: no kernel for this fmt/rmode/dtype
 
 int g_max_blocks = 0;
 thread_local char g_err[256] = "";
@@ -54,36 +55,6 @@ struct CastParams {
   uint64_t seed, offset;
   uint64_t elem_base;         // global index of element 0 of this buffer
 };
-
-template <int DT> struct Storage;
-template <> struct Storage<FPEMU_F32> { static constexpr unsigned V = 4; using elem = float; };
-template <> struct Storage<FPEMU_F16> { static constexpr unsigned V = 8; using elem = uint16_t; };
-template <> struct Storage<FPEMU_BF16> { static constexpr unsigned V = 8; using elem = uint16_t; };
-
-__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-  uint32_t u = f2u(f);
-  const uint32_t rn = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-  const uint32_t nan = (u >> 16) | 0x0040u;
-  return ((u & 0x7FFFFFFFu) > 0x7F800000u) ? nan : rn;
-}
-
-// Streaming 16-byte store with the "sc1 nt" policy bits (write-through, non-temporal): measured
-// +2 % over a plain nt store on MI355X for this read-once / write-once stream (tools/sweep.hip);
-// the builtin only offers "nt".  Vector store only; nothing in the launch reads it back.
-// The trailing s_nop 1 is required: hipcc pads no hazards inside an asm statement, and a VALU
-// write to the data registers right after a >64-bit store would overtake the store's read of them.
-__device__ __forceinline__ void store_stream(u32x4 *p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
-
-template <int DT> __device__ __forceinline__ float load_elem16(uint32_t b) {
-  if constexpr (DT == FPEMU_F16) return h_to_f32(b);
-  else return u2f(b << 16);
-}
-template <int DT> __device__ __forceinline__ uint32_t store_elem16(float f) {
-  if constexpr (DT == FPEMU_F16) return f32_to_h(f);
-  else return f32_to_bf16_bits(f);
-}
 
 // Random bits for element e (0..V-1) of slot s from the lane's Philox results of this superblock.
 template <int FMT, unsigned V, int NCALLS>
@@ -173,26 +144,6 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out
 // amax: unsigned max over |x| bit patterns; wave64 butterfly, one LDS word per wave, one
 // device-scope atomic per block.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t m) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64);
-    m = m > o ? m : o;
-  }
-  return m;
-}
-
-template <int DT> __device__ __forceinline__ uint32_t absmax_word(uint32_t m, uint32_t w) {
-  if constexpr (DT == FPEMU_F32) {
-    const uint32_t a = w & 0x7FFFFFFFu;
-    return m > a ? m : a;
-  } else {
-    const uint32_t a = w & 0x7FFFu, b = (w >> 16) & 0x7FFFu;
-    const uint32_t c = a > b ? a : b;
-    return m > c ? m : c;
-  }
-}
-
 constexpr int kAmaxVPT = 8;  // 16-byte vectors in flight per lane
 
 template <int DT>
@@ -251,85 +202,6 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// rows: per-row amax -> scale -> cast of a contiguous [rows, cols] buffer in ONE launch.
-// Replaces the reference's Python loop over channels (qutils.py:289-311: per row a torch.max, a
-// host-synchronising scale computation and one cast launch) and, with clamp = 0 and
-// rows = out_channels x groups, its fine-grained loop (qutils.py:313-337).
-// One 256-thread block per row: pass 1 reduces |x| over the row (plain loads, so the row stays
-// in L2 for pass 2), wave64 butterfly + one LDS word per wave, every thread derives the row's
-// scale, pass 2 re-reads and casts.  VEC = rows are 16-byte aligned (cols % V == 0).
-// Stochastic noise: row r is "call offset + r", element index = column, exactly what a loop of
-// per-row casts with consecutive offsets draws.
-// ---------------------------------------------------------------------------------------------
-template <int FMT, int RM, int DT, bool VEC>
-__global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out_, uint64_t cols,
-                                                      float flt_max, int clamp, uint64_t seed,
-                                                      uint64_t offset, uint32_t *amax_out) {
-  constexpr unsigned V = Storage<DT>::V;
-  constexpr bool SR = (RM == STOCHASTIC);
-  using elem_t = typename Storage<DT>::elem;
-  const uint64_t row = blockIdx.x;
-  const elem_t *ein = reinterpret_cast<const elem_t *>(in_) + row * cols;
-  elem_t *eout = reinterpret_cast<elem_t *>(out_) + row * cols;
-  const u32x4 *vin = reinterpret_cast<const u32x4 *>(ein);
-  u32x4 *vout = reinterpret_cast<u32x4 *>(eout);
-  const uint64_t nvec = VEC ? cols / V : 0;
-
-  uint32_t m = 0u;
-  for (uint64_t i = threadIdx.x; i < nvec; i += kBlock) {
-    const u32x4 v = vin[i];
-#pragma unroll
-    for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, v[j]);
-  }
-  for (uint64_t e = nvec * V + threadIdx.x; e < cols; e += kBlock) {
-    if constexpr (DT == FPEMU_F32) m = absmax_word<DT>(m, f2u(ein[e]));
-    else m = absmax_word<DT>(m, (uint32_t)ein[e]);
-  }
-  m = wave_max_u32(m);
-  __shared__ uint32_t part[kWavesPerBlock];
-  if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  uint32_t r = part[0];
-#pragma unroll
-  for (int w = 1; w < kWavesPerBlock; w++) r = r > part[w] ? r : part[w];
-  if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
-  else if constexpr (DT == FPEMU_BF16) r = r << 16;
-  if (amax_out != nullptr && threadIdx.x == 0) amax_out[row] = r;
-  const float scale = scale_from_amax(r, flt_max, clamp != 0);
-  const float rcp = scale_reciprocal(scale);
-  const uint64_t roff = offset + row;
-
-  for (uint64_t i = threadIdx.x; i < nvec; i += kBlock) {
-    const u32x4 v = vin[i];
-    u32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if constexpr (DT == FPEMU_F32) {
-        uint32_t rnd = 0u;
-        if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, i * V + j);
-        o[j] = f2u(cast_one<FMT, RM>(u2f(v[j]), scale, rcp, rnd));
-      } else {
-        uint32_t r0 = 0u, r1 = 0u;
-        if constexpr (SR) {
-          r0 = rand_bits_elem<FMT, V>(seed, roff, i * V + 2 * j);
-          r1 = rand_bits_elem<FMT, V>(seed, roff, i * V + 2 * j + 1);
-        }
-        const float y0 = cast_one<FMT, RM>(load_elem16<DT>(v[j] & 0xFFFFu), scale, rcp, r0);
-        const float y1 = cast_one<FMT, RM>(load_elem16<DT>(v[j] >> 16), scale, rcp, r1);
-        o[j] = (store_elem16<DT>(y0) & 0xFFFFu) | (store_elem16<DT>(y1) << 16);
-      }
-    }
-    vout[i] = o;
-  }
-  for (uint64_t e = nvec * V + threadIdx.x; e < cols; e += kBlock) {
-    uint32_t rnd = 0u;
-    if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, e);
-    if constexpr (DT == FPEMU_F32) eout[e] = cast_one<FMT, RM>(ein[e], scale, rcp, rnd);
-    else eout[e] = (elem_t)store_elem16<DT>(cast_one<FMT, RM>(load_elem16<DT>(ein[e]), scale, rcp, rnd));
-  }
-}
-
 // One-word reset ahead of an amax accumulation: a kernel launch costs the host ~3 us where
 // hipMemsetAsync costs >10 us on this runtime, and the small-tensor regime is host-bound.
 __global__ void zero_word_kernel(uint32_t *w) { *w = 0u; }
@@ -351,32 +223,10 @@ template <int DT> cast_fn pick_cast(int fmt, int rm) {
   FPEMU_CASE(BF16, RTZ) FPEMU_CASE(BF16, RNE) FPEMU_CASE(BF16, STOCHASTIC)
   FPEMU_CASE(FP16, RNE) FPEMU_CASE(FP16, STOCHASTIC)
   FPEMU_CASE(FP16_DAZ, RNE)
+  FPEMU_CASE(E4M3_IEEE, RNE) FPEMU_CASE(E4M3_IEEE, STOCHASTIC)
+  FPEMU_CASE(FP4, RNE)
 #undef FPEMU_CASE
   return nullptr;
-}
-
-typedef void (*rows_fn)(const void *, void *, uint64_t, float, int, uint64_t, uint64_t, uint32_t *);
-
-template <int DT, bool VEC> rows_fn pick_rows(int fmt, int rm) {
-#define FPEMU_CASE(F, R) \
-  if (fmt == F && rm == R) return rows_kernel<F, R, DT, VEC>;
-  FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
-  FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
-  FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
-  FPEMU_CASE(E5M2_DAZ, RNTZ)
-  FPEMU_CASE(E4M3, RTZ) FPEMU_CASE(E4M3, RNE) FPEMU_CASE(E4M3, STOCHASTIC)
-  FPEMU_CASE(E3M4, RTZ) FPEMU_CASE(E3M4, RNE) FPEMU_CASE(E3M4, STOCHASTIC)
-#undef FPEMU_CASE
-  return nullptr;  // BF16 / FP16 take no scale: per-row scaling is meaningless for them
-}
-
-rows_fn pick_rows_dt(int dtype, bool vec, int fmt, int rm) {
-  switch (dtype) {
-    case FPEMU_F32: return vec ? pick_rows<FPEMU_F32, true>(fmt, rm) : pick_rows<FPEMU_F32, false>(fmt, rm);
-    case FPEMU_F16: return vec ? pick_rows<FPEMU_F16, true>(fmt, rm) : pick_rows<FPEMU_F16, false>(fmt, rm);
-    case FPEMU_BF16: return vec ? pick_rows<FPEMU_BF16, true>(fmt, rm) : pick_rows<FPEMU_BF16, false>(fmt, rm);
-    default: return nullptr;
-  }
 }
 
 cast_fn pick_cast_dt(int dtype, int fmt, int rm) {
@@ -388,8 +238,6 @@ cast_fn pick_cast_dt(int dtype, int fmt, int rm) {
   }
 }
 
-unsigned elem_size(int dtype) { return dtype == FPEMU_F32 ? 4u : 2u; }
-unsigned vec_elems(int dtype) { return dtype == FPEMU_F32 ? 4u : 8u; }
 
 int max_blocks() { return g_max_blocks > 0 ? g_max_blocks : kDefaultMaxBlocks; }
 
@@ -462,6 +310,9 @@ int fpemu_parse_mode(const char *mode, int *fmt, int *rmode) {
       {"E4M3_RTZ", E4M3, RTZ},
       {"E3M4_RTZ", E3M4, RTZ},
       {"BFLOAT16_RTZ", BF16, RTZ},
+      {"E4M3_IEEE_RNE", E4M3_IEEE, RNE},
+      {"E4M3_IEEE_STOCHASTIC", E4M3_IEEE, STOCHASTIC},
+      {"FP4_NEAREST", FP4, RNE},
   };
   if (mode == nullptr || fmt == nullptr || rmode == nullptr)
     return fail(FPEMU_EINVAL, "fpemu_parse_mode: null argument");
@@ -472,9 +323,6 @@ int fpemu_parse_mode(const char *mode, int *fmt, int *rmode) {
       return FPEMU_OK;
     }
   }
-  if (!strcmp(mode, "E4M3_IEEE_RNE") || !strcmp(mode, "E4M3_IEEE_STOCHASTIC") ||
-      !strcmp(mode, "FP4_NEAREST"))
-    return fail(FPEMU_EUNSUPPORTED, "fpemu: mode exists in the reference but is outside this build's scope");
   return fail(FPEMU_EMODE, "fpemu: unknown mode string");
 }
 
@@ -501,7 +349,11 @@ int fpemu_forward(const void *in, void *out, int dtype, const char *mode, uint64
   if (rc != FPEMU_OK) return rc;
   if (block_norm && block_size > 0 && (uint64_t)block_size != size && (size % (uint64_t)block_size) != 0)
     block_norm = 0;  // cpp:2020-2025
-  if (block_norm) return fail(FPEMU_EUNSUPPORTED, "fpemu_forward: block_norm is not implemented");
+  // formats whose reference kernel has a block-norm branch; the others ignore the flag (cpp:1913-1957)
+  if (block_norm && block_size > 0 && (fmt == E5M2 || fmt == E4M3 || fmt == E3M4 || fmt == E4M3_IEEE || fmt == FP4)) {
+    if (scale > 3.402823466e+38f) return fail(FPEMU_EINVAL, "fpemu_forward: invalid scale factor (inf)");
+    return fpemu_quantize_blocks(in, out, size, (uint64_t)block_size, dtype, fmt, rmode, seed, offset, stream);
+  }
   return fpemu_cast(in, out, size, dtype, fmt, rmode, scale, seed, offset, 0, stream);
 }
 
@@ -557,15 +409,9 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
   // at `offset` is exactly the flat layout's, so results do not depend on which path ran.
   if (n <= kSmallTensor && in != nullptr && out != nullptr && dtype >= FPEMU_F32 && dtype <= FPEMU_BF16 &&
       ((uintptr_t)in % elem_size(dtype)) == 0 && ((uintptr_t)out % elem_size(dtype)) == 0) {
-    const bool vec = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (n % vec_elems(dtype)) == 0;
-    rows_fn fn = pick_rows_dt(dtype, vec, fmt, rmode);
-    if (fn != nullptr) {
-      hipLaunchKernelGGL(fn, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, in, out, n, flt_max, clamp,
-                         seed, offset, amax_ws);
-      hipError_t e1 = hipGetLastError();
-      if (e1 != hipSuccess) return fail((int)e1, hipGetErrorString(e1));
-      return FPEMU_OK;
-    }
+    const int rc1 = fpemu_rows_launch_(in, out, 1, n, dtype, fmt, rmode, flt_max, clamp ? 1 : 0, seed, offset,
+                                       amax_ws, /*force_block=*/1, stream);
+    if (rc1 != kNoRowsKernel) return rc1;  // formats without a scale fall through to the flat path
   }
   hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax_ws);
   hipError_t e = hipGetLastError();
@@ -585,15 +431,32 @@ int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols,
   const unsigned es = elem_size(dtype);
   if (((uintptr_t)in % es) || ((uintptr_t)out % es))
     return fail(FPEMU_EALIGN, "fpemu_quantize_rows: buffer not aligned to its element size");
-  const bool vec = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % vec_elems(dtype)) == 0;
-  rows_fn fn = pick_rows_dt(dtype, vec, fmt, rmode);
-  if (fn == nullptr)
+  const int rc = fpemu_rows_launch_(in, out, rows, cols, dtype, fmt, rmode, flt_max, clamp ? 1 : 0, seed, offset,
+                                    nullptr, 0, stream);
+  if (rc == kNoRowsKernel)
     return fail(FPEMU_EINVAL, "fpemu_quantize_rows: format / rounding-mode pair takes no scale or is not defined");
-  hipLaunchKernelGGL(fn, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, in, out, cols,
-                     flt_max, clamp, seed, offset, (uint32_t *)nullptr);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-  return FPEMU_OK;
+  return rc;
+}
+
+int fpemu_quantize_blocks(const void *in, void *out, uint64_t n, uint64_t block_size, int dtype, int fmt,
+                          int rmode, uint64_t seed, uint64_t offset, void *stream) {
+  if (n == 0) return FPEMU_OK;
+  if (in == nullptr || out == nullptr) return fail(FPEMU_EINVAL, "fpemu_quantize_blocks: null buffer");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_quantize_blocks: bad dtype id");
+  if (block_size == 0 || (n % block_size) != 0)
+    return fail(FPEMU_EINVAL, "fpemu_quantize_blocks: size is not a multiple of block_size");
+  if (!(fmt == E5M2 || fmt == E4M3 || fmt == E3M4 || fmt == E4M3_IEEE || fmt == FP4))
+    return fail(FPEMU_EINVAL, "fpemu_quantize_blocks: the reference defines no block norm for this format");
+  const uint64_t rows = n / block_size;
+  if (rows > 0x7FFFFFFFull) return fail(FPEMU_EINVAL, "fpemu_quantize_blocks: more than 2^31-1 blocks");
+  const unsigned es = elem_size(dtype);
+  if (((uintptr_t)in % es) || ((uintptr_t)out % es))
+    return fail(FPEMU_EALIGN, "fpemu_quantize_blocks: buffer not aligned to its element size");
+  const int rc = fpemu_rows_launch_(in, out, rows, block_size, dtype, fmt, rmode, 0.f, /*block norm*/ 2, seed,
+                                    offset, nullptr, 0, stream);
+  if (rc == kNoRowsKernel)
+    return fail(FPEMU_EINVAL, "fpemu_quantize_blocks: format / rounding-mode pair not defined");
+  return rc;
 }
 
 }  // extern "C"

@@ -1,0 +1,173 @@
+// fpemu_rows.hip -- per-row amax -> scale -> cast of a contiguous [rows, cols] buffer in ONE launch.
+//
+// Replaces three loops of the reference, all "reduce max |x| over a contiguous run, derive a scale,
+// cast the run with it":
+//   * the Python loop over channels (qutils.py:289-311: per row a torch.max, a host-synchronising scale
+//     computation and one cast launch) -- policy kRowsClamp;
+//   * the fine-grained loop over out_channels x groups (qutils.py:313-337) -- policy kRowsNoClamp;
+//   * block normalisation inside the native kernels (block_norm = true: cpp/fpemu_impl.cpp:778-815,
+//     :1149-1190, :1441-1478, :1734-1770, :1840-1860) -- policy kRowsBlockNorm, rows = blocks.
+//
+// Team per row (TEAM): a 256-thread block; one wave64, four rows per block (rows of <= kWaveRowCols
+// elements: conv filters, block-norm blocks); or a single lane, 256 rows per block (rows of
+// <= kLaneRowCols elements -- the reference's emulators call block norm with block_size = 1 on embedding
+// tables, hybrid_emu.py:119: one "block" per element).  Pass 1 reduces |x| over the row
+// (plain loads, so the row stays in L2 for pass 2), wave64 butterfly (+ one LDS word per wave for block
+// teams), every thread derives the row's scale, pass 2 re-reads and casts.  VEC = rows are 16-byte
+// aligned (cols % V == 0).  Stochastic noise: row r is "call offset + r", element index = column, exactly
+// what a loop of per-row casts with consecutive offsets draws.
+#include "fpemu_common.hpp"
+
+using namespace fpemu;
+
+namespace {
+
+enum { kRowsNoClamp = 0, kRowsClamp = 1, kRowsBlockNorm = 2 };
+constexpr uint64_t kWaveRowCols = 1024;
+constexpr uint64_t kLaneRowCols = 16;
+
+// |x| pattern for the running max.  Block norm compares floats with `maxval < fabs(x)`, which never
+// takes a NaN (cpp:791-793); torch.max (the per-channel callers) propagates it.
+template <int DT> __device__ __forceinline__ uint32_t drop_nan(uint32_t w) {
+  if constexpr (DT == FPEMU_F32) {
+    return ((w & 0x7FFFFFFFu) > 0x7F800000u) ? 0u : w;
+  } else {
+    constexpr uint32_t INF = DT == FPEMU_F16 ? 0x7C00u : 0x7F80u;
+    const uint32_t a = ((w & 0x7FFFu) > INF) ? 0u : (w & 0xFFFFu);
+    const uint32_t b = (((w >> 16) & 0x7FFFu) > INF) ? 0u : (w >> 16);
+    return a | (b << 16);
+  }
+}
+
+template <int FMT, int RM, int DT, bool VEC, int TEAM>
+__global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out_, uint64_t rows,
+                                                      uint64_t cols, float flt_max, int policy,
+                                                      uint64_t seed, uint64_t offset, uint32_t *amax_out) {
+  constexpr unsigned V = Storage<DT>::V;
+  constexpr bool SR = (RM == STOCHASTIC);
+  static_assert(TEAM == 1 || TEAM == 64 || TEAM == kBlock, "team = lane, wave or block");
+  constexpr unsigned TS = (unsigned)TEAM;  // team size
+  using elem_t = typename Storage<DT>::elem;
+  const unsigned t = TEAM == 1 ? 0u : TEAM == 64 ? (threadIdx.x & 63u) : threadIdx.x;
+  const uint64_t row = TEAM == 1    ? (uint64_t)blockIdx.x * kBlock + threadIdx.x
+                       : TEAM == 64 ? (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)
+                                    : (uint64_t)blockIdx.x;
+  if (TEAM != kBlock && row >= rows) return;  // only the block team has a barrier below
+  const elem_t *ein = reinterpret_cast<const elem_t *>(in_) + row * cols;
+  elem_t *eout = reinterpret_cast<elem_t *>(out_) + row * cols;
+  const u32x4 *vin = reinterpret_cast<const u32x4 *>(ein);
+  u32x4 *vout = reinterpret_cast<u32x4 *>(eout);
+  const uint64_t nvec = (VEC && TEAM != 1) ? cols / V : 0;  // a lone lane walks its short row by element
+  const bool bn = (policy == kRowsBlockNorm);
+
+  uint32_t m = 0u;
+  for (uint64_t i = t; i < nvec; i += TS) {
+    const u32x4 v = vin[i];
+#pragma unroll
+    for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, bn ? drop_nan<DT>(v[j]) : v[j]);
+  }
+  // (a lone lane's loop is unit-stride: keep the loop vectoriser off it, it cannot select the result)
+#pragma clang loop vectorize(disable) interleave(disable)
+  for (uint64_t e = nvec * V + t; e < cols; e += TS) {
+    uint32_t w;
+    if constexpr (DT == FPEMU_F32) w = f2u(ein[e]);
+    else w = (uint32_t)ein[e];
+    m = absmax_word<DT>(m, bn ? drop_nan<DT>(w) : w);
+  }
+  uint32_t r = m;
+  if constexpr (TEAM != 1) r = wave_max_u32(m);
+  if constexpr (TEAM == kBlock) {
+    __shared__ uint32_t part[kWavesPerBlock];
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = r;
+    __syncthreads();
+    r = part[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; w++) r = r > part[w] ? r : part[w];
+  }
+  if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
+  else if constexpr (DT == FPEMU_BF16) r = r << 16;
+  if (amax_out != nullptr && t == 0) amax_out[row] = r;
+  const float scale = bn ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
+  const float rcp = scale_reciprocal(scale);
+  const uint64_t roff = offset + row;
+
+  for (uint64_t i = t; i < nvec; i += TS) {
+    const u32x4 v = vin[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if constexpr (DT == FPEMU_F32) {
+        uint32_t rnd = 0u;
+        if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, i * V + j);
+        o[j] = f2u(cast_one<FMT, RM>(u2f(v[j]), scale, rcp, rnd));
+      } else {
+        uint32_t r0 = 0u, r1 = 0u;
+        if constexpr (SR) {
+          r0 = rand_bits_elem<FMT, V>(seed, roff, i * V + 2 * j);
+          r1 = rand_bits_elem<FMT, V>(seed, roff, i * V + 2 * j + 1);
+        }
+        const float y0 = cast_one<FMT, RM>(load_elem16<DT>(v[j] & 0xFFFFu), scale, rcp, r0);
+        const float y1 = cast_one<FMT, RM>(load_elem16<DT>(v[j] >> 16), scale, rcp, r1);
+        o[j] = (store_elem16<DT>(y0) & 0xFFFFu) | (store_elem16<DT>(y1) << 16);
+      }
+    }
+    vout[i] = o;
+  }
+#pragma clang loop vectorize(disable) interleave(disable)
+  for (uint64_t e = nvec * V + t; e < cols; e += TS) {
+    uint32_t rnd = 0u;
+    if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, e);
+    if constexpr (DT == FPEMU_F32) eout[e] = cast_one<FMT, RM>(ein[e], scale, rcp, rnd);
+    else eout[e] = (elem_t)store_elem16<DT>(cast_one<FMT, RM>(load_elem16<DT>(ein[e]), scale, rcp, rnd));
+  }
+}
+
+typedef void (*rows_fn)(const void *, void *, uint64_t, uint64_t, float, int, uint64_t, uint64_t, uint32_t *);
+
+template <int DT, bool VEC, int TEAM> rows_fn pick_rows(int fmt, int rm) {
+#define FPEMU_CASE(F, R) \
+  if (fmt == F && rm == R) return rows_kernel<F, R, DT, VEC, TEAM>;
+  FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
+  FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
+  FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
+  FPEMU_CASE(E5M2_DAZ, RNTZ)
+  FPEMU_CASE(E4M3, RTZ) FPEMU_CASE(E4M3, RNE) FPEMU_CASE(E4M3, STOCHASTIC)
+  FPEMU_CASE(E3M4, RTZ) FPEMU_CASE(E3M4, RNE) FPEMU_CASE(E3M4, STOCHASTIC)
+  FPEMU_CASE(E4M3_IEEE, RNE) FPEMU_CASE(E4M3_IEEE, STOCHASTIC)
+  FPEMU_CASE(FP4, RNE)
+#undef FPEMU_CASE
+  return nullptr;  // BF16 / FP16 take no scale: per-row scaling is meaningless for them
+}
+
+template <int DT> rows_fn pick_rows_dt(bool vec, int team, int fmt, int rm) {
+  if (team == 1) return pick_rows<DT, false, 1>(fmt, rm);
+  if (team == 64) return vec ? pick_rows<DT, true, 64>(fmt, rm) : pick_rows<DT, false, 64>(fmt, rm);
+  return vec ? pick_rows<DT, true, kBlock>(fmt, rm) : pick_rows<DT, false, kBlock>(fmt, rm);
+}
+
+}  // namespace
+
+// Internal to the library (declared in fpemu_hip.hip).  Arguments are validated by the callers except
+// for what depends on the kernel choice.  force_block: always one block per row (the per-tensor small
+// path: one row of up to 32 Ki elements).
+extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype,
+                                  int fmt, int rmode, float flt_max, int policy, uint64_t seed,
+                                  uint64_t offset, uint32_t *amax_out, int force_block, void *stream) {
+  const bool vec = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % vec_elems(dtype)) == 0;
+  const int team = (force_block || rows == 1 || cols > kWaveRowCols) ? kBlock : cols > kLaneRowCols ? 64 : 1;
+  rows_fn fn = dtype == FPEMU_F32 ? pick_rows_dt<FPEMU_F32>(vec, team, fmt, rmode)
+             : dtype == FPEMU_F16 ? pick_rows_dt<FPEMU_F16>(vec, team, fmt, rmode)
+             : dtype == FPEMU_BF16 ? pick_rows_dt<FPEMU_BF16>(vec, team, fmt, rmode) : nullptr;
+  if (fn == nullptr) return -100;  // kNoRowsKernel of fpemu_hip.hip
+  const uint64_t per_block = team == 1 ? (uint64_t)kBlock : team == 64 ? (uint64_t)kWavesPerBlock : 1u;
+  const uint64_t blocks = (rows + per_block - 1) / per_block;
+  if (blocks > 0x7FFFFFFFull) return FPEMU_EINVAL;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, in, out, rows, cols,
+                     flt_max, policy, seed, offset, amax_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fpemu_set_error_(hipGetErrorString(e));
+    return (int)e;
+  }
+  return FPEMU_OK;
+}

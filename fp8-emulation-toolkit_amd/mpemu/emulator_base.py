@@ -13,9 +13,10 @@ Divergences from the reference (deliberate):
     RuntimeError unless the optimizer went through amp.initialize, hybrid_emu.py:69-79);
   * blacklist_modules / whitelist_modules pass the model to create_or_update_hooks (the reference
     omits the argument and raises TypeError, e5m2_emu.py:89);
-  * tensorboard statistics and binary tensor dumps are accepted as settings and ignored;
-  * `emb_norm` (block-normalised embedding tables) raises NotImplementedError: block_norm is
-    outside this build's scope.
+  * tensorboard statistics and binary tensor dumps are accepted as settings and ignored.
+`emb_norm` keeps the reference's call exactly, including its positional slip: FPEmuOp.apply(param, mode,
+True, emb_norm, cols) binds scale=emb_norm and blocknorm=cols, blocksize=1 (hybrid_emu.py:119), i.e. block
+norm with one element per block -- that is what the reference executes, so that is what runs here.
 """
 import torch
 
@@ -123,8 +124,12 @@ class EmulatorBase(object):
             param.data = fpemu_cuda.FPEmuOp.apply(param.data, "FLOAT16_STOCHASTIC", True)
             if self.emb_master_mode is not None and "embeddings" in name:
                 if self.emb_norm:
-                    raise NotImplementedError("block-normalised embedding tables (emb_norm) are not implemented")
-                param.data = fpemu_cuda.FPEmuOp.apply(param.data, self.emb_master_mode, True)
+                    # (1-D "embeddings" parameters such as LayerNorm weights: the reference's
+                    # param.size()[1] raises IndexError; only the value's truth is used, so pass 1)
+                    cols = param.size()[1] if param.dim() > 1 else 1
+                    param.data = fpemu_cuda.FPEmuOp.apply(param.data, self.emb_master_mode, True, self.emb_norm, cols)
+                else:
+                    param.data = fpemu_cuda.FPEmuOp.apply(param.data, self.emb_master_mode, True)
 
     def update_e5m2_master_params(self, optimizer):
         from .pytquant import fpemu_cuda

@@ -65,7 +65,9 @@ def lib():
         L.fpemu_gemm_f32.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, i32, i32, i32, vp]
         L.fpemu_set_max_blocks.restype = None
         L.fpemu_set_max_blocks.argtypes = [i32]
-        if L.fpemu_abi_version() != 1:
+        L.fpemu_quantize_blocks.restype = i32
+        L.fpemu_quantize_blocks.argtypes = [vp, vp, u64, u64, i32, i32, i32, u64, u64, vp]
+        if L.fpemu_abi_version() != 2:
             raise ImportError("libfpemu_hip.so: ABI version mismatch")
         _lib = L
     return _lib
@@ -238,6 +240,27 @@ def quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=True):
     return dst
 
 
+_BLOCKNORM_FMTS = (0, 1, 2, 7, 8)  # E5M2, E4M3, E3M4, E4M3_IEEE, FP4: reference kernels with a block_norm branch
+
+
+def quantize_blocks_(src, dst, block_size, fmt, rmode):
+    """Block-normalised cast (forward(..., block_norm=True, block_size) of the reference): per block of
+    block_size consecutive elements the scale comes from the block's max |x|; one launch."""
+    global _offset
+    _require_device(src)
+    _require_device(dst, "output")
+    n = src.numel()
+    if block_size <= 0 or n % block_size:
+        raise ValueError("fpemu: %d elements do not split into blocks of %d" % (n, block_size))
+    off = _offset
+    if rmode == STOCHASTIC:
+        _offset += n // block_size
+    with _on_device(src):
+        _check(lib().fpemu_quantize_blocks(src.data_ptr(), dst.data_ptr(), n, block_size, _dtype_id(src), fmt,
+                                           rmode, _seed, off, _stream(src)))
+    return dst
+
+
 GEMM_SEPARATE, GEMM_FMA = 0, 1
 
 
@@ -270,11 +293,14 @@ def forward(input, mode, size, inplace, scale, block_norm=False, block_size=1):
     _require_device(input)
     if int(size) != input.numel():
         raise ValueError("fpemu.forward: size (%d) != input.numel() (%d)" % (size, input.numel()))
-    _, rmode = parse_mode(mode)
+    fmt, rmode = parse_mode(mode)
     out = input if inplace else torch.empty_like(input)
+    n, bs = input.numel(), int(block_size)
+    if block_norm and bs > 0 and n > 0 and (bs == n or n % bs == 0) and fmt in _BLOCKNORM_FMTS:
+        return [quantize_blocks_(input, out, bs, fmt, rmode)]  # cpp:2020-2025: otherwise demoted
     with _on_device(input):
         _check(lib().fpemu_forward(input.data_ptr(), out.data_ptr(), _dtype_id(input), str(mode).encode(),
-                                   input.numel(), float(scale), int(bool(block_norm)), int(block_size),
+                                   input.numel(), float(scale), 0, 1,
                                    _seed, _next_offset(rmode), _stream(input)))
     return [out]
 

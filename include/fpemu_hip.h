@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FPEMU_ABI_VERSION 1
+#define FPEMU_ABI_VERSION 2
 
 /* Storage dtype of in/out buffers. */
 enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
@@ -39,7 +39,10 @@ enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
  *   BF16      BFLOAT16_Kernel    cpp/fpemu_impl.cpp:331   (RNE :207-232, SR :284-329)
  *   FP16      FLOAT16_Kernel     cpp/fpemu_impl.cpp:356
  *   E5M2_DAZ  E5M2_DAZ_Kernel    cpp/fpemu_impl.cpp:846
- *   FP16_DAZ  FLOAT16_Kernel with no_denorm=1 (cpp:1943-1947) */
+ *   FP16_DAZ  FLOAT16_Kernel with no_denorm=1 (cpp:1943-1947)
+ *   E4M3_IEEE E4M3_IEEE_Kernel   cpp/fpemu_impl.cpp:1428  (max 240; the AVX-512 routines :1213-1328 are
+ *                                canonical: the scalar routine saturates from 15.0 on, :1364)
+ *   FP4       FP4_Nearest_Kernel cpp/fpemu_impl.cpp:1827  (:1797-1824; rounding-mode id FPEMU_RNE) */
 enum {
   FPEMU_FMT_E5M2 = 0,
   FPEMU_FMT_E4M3 = 1,
@@ -47,7 +50,9 @@ enum {
   FPEMU_FMT_BF16 = 3,
   FPEMU_FMT_FP16 = 4,
   FPEMU_FMT_E5M2_DAZ = 5,
-  FPEMU_FMT_FP16_DAZ = 6
+  FPEMU_FMT_FP16_DAZ = 6,
+  FPEMU_FMT_E4M3_IEEE = 7,
+  FPEMU_FMT_FP4 = 8
 };
 
 /* Rounding mode: the reference's enum ROUNDING_MODES, cpp/fpemu_impl.cpp:15-23. */
@@ -66,7 +71,7 @@ enum {
   FPEMU_OK = 0,
   FPEMU_EINVAL = -1,       /* null pointer, bad dtype/fmt/rmode id, non-finite scale */
   FPEMU_EMODE = -2,        /* mode string not recognised (the reference silently no-ops) */
-  FPEMU_EUNSUPPORTED = -3, /* recognised but not built: block_norm, E4M3_IEEE_*, FP4_NEAREST */
+  FPEMU_EUNSUPPORTED = -3, /* recognised but not built (no such case at present) */
   FPEMU_EALIGN = -4        /* pointer not aligned to the element size */
 };
 
@@ -76,8 +81,7 @@ const char *fpemu_last_error(void);
 /* Mode-string dispatcher: replaces the if/else chain of fpemu_common_function
  * (cpp/fpemu_impl.cpp:1878-2000; hip/fpemu_kernels.hip:1069-1386).  Accepts every string the
  * reference dispatches plus the three RTZ extensions BASELINE.json names (E4M3_RTZ, E3M4_RTZ,
- * BFLOAT16_RTZ).  Returns FPEMU_EMODE for an unknown string, FPEMU_EUNSUPPORTED for
- * E4M3_IEEE_* and FP4_NEAREST. */
+ * BFLOAT16_RTZ).  Returns FPEMU_EMODE for an unknown string. */
 int fpemu_parse_mode(const char *mode, int *fmt, int *rmode);
 
 /* The cast itself: out[i] = dequant(quant_fmt(in[i] * scale)) * (1/scale), i in [0, n).
@@ -92,9 +96,10 @@ int fpemu_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rm
                uint64_t seed, uint64_t offset, uint64_t elem_base, void *stream);
 
 /* Mirror of the pybind `forward` signature (hip/fpemu_impl.cpp:27-37): mode string, size,
- * scale, block_norm, block_size.  inplace <=> out == in.  block_norm with a usable block_size
- * returns FPEMU_EUNSUPPORTED; like the reference (cpp:2020-2025) it is demoted to false when
- * size % block_size != 0. */
+ * scale, block_norm, block_size.  inplace <=> out == in.  block_norm: as the reference
+ * (cpp:2020-2025) demoted to false when block_size != size and size % block_size != 0; otherwise
+ * fpemu_quantize_blocks for the formats that have the branch, ignored (plain cast) by the others
+ * (E5M2_DAZ, BFLOAT16, FLOAT16: their reference kernels take no block_norm). */
 int fpemu_forward(const void *in, void *out, int dtype, const char *mode, uint64_t size,
                   float scale, int block_norm, int block_size, uint64_t seed, uint64_t offset,
                   void *stream);
@@ -131,6 +136,18 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
 int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt,
                         int rmode, float flt_max, int clamp, uint64_t seed, uint64_t offset,
                         void *stream);
+
+/* Block-normalised cast: the reference's forward(..., block_norm = true, block_size) for the formats
+ * whose kernels have that branch (E5M2_Kernel cpp/fpemu_impl.cpp:778-815, E4M3_Kernel :1149-1190,
+ * E4M3_IEEE_Kernel :1441-1478, E3M4_Kernel :1734-1770, FP4_Nearest_Kernel :1840-1860).  The buffer is
+ * n / block_size consecutive blocks; per block: maxval = max |x| (a NaN is never taken), p2 = maxval
+ * with its mantissa cleared, scale = 2*p2/16384 (E5M2) | 2*p2/8 (E4M3, E4M3_IEEE) | 2*p2 (E3M4) |
+ * 1/maxval (FP4), then the ordinary cast of the block.  One launch for all blocks.
+ * n % block_size must be 0 (fpemu_forward applies the reference's demotion rule, cpp:2020-2025, before
+ * calling this).  Stochastic modes: block b draws as call `offset + b`, element index = position in
+ * the block. */
+int fpemu_quantize_blocks(const void *in, void *out, uint64_t n, uint64_t block_size, int dtype, int fmt,
+                          int rmode, uint64_t seed, uint64_t offset, void *stream);
 
 /* cmodel emulated GEMM ("next" row of the hot path; BASELINE config 5).  Replaces the reference's CPU
  * cmodel entry point  simple_gemm_dev.gemm(C, A, B, alpha, a_trans, b_trans)

@@ -168,8 +168,61 @@ static uint16_t q_e4m3_e3m4(uint16_t h, int rmode, uint32_t rnd, int k, uint32_t
   return (uint16_t)mant;
 }
 
+/* E4M3_IEEE: cvt_fp32_e4m3_ieee_rne_intrinsic cpp:1213-1265 and ..._stochastic_intrinsic cpp:1267-1328,
+ * the AVX-512 routines, which are canonical here: the scalar routine tests can_round against 0x4B80
+ * (15.0) instead of 0x5B80 (cpp:1364) and so saturates everything >= 15 to 240 -- a reference bug the
+ * bulk (size/32*32) of every tensor never sees on an AVX-512 host.  Same shape as E4M3 with max 240
+ * (0x5B80); NaN and Inf saturate; under STOCHASTIC the pseudo-subnormal range (< 2^-6) rounds RNE. */
+static uint16_t q_e4m3_ieee(uint16_t h, int rmode, uint32_t rnd) {
+  uint32_t a = h;
+  uint32_t ef = a & 0x7C00u;
+  int not_naninf = (ef != 0x7C00u);                 /* maska1 */
+  uint32_t fix = (a & 0x0080u) ? 1u : 0u;           /* maska2: kept LSB, makes 0x3f+1 the tie-to-even add */
+  int sat = ((a & 0x7FFFu) >= 0x5B80u);             /* maska3 */
+  int flush = (ef < 0x1800u);                       /* maska4 */
+  int sub = (ef < 0x2400u);                         /* maska5 */
+  if (sub) {
+    unsigned sh = 9u - (ef >> 10);                  /* cpp:1243-1248 */
+    a = ((a >> sh) << sh) & 0xFFFFu;
+  }
+  uint32_t r = a;
+  if (rmode == ORC_STOCHASTIC) {
+    if (not_naninf && !sub) r = a + (rnd & 0x7Fu);  /* cpp:1312-1313: 7 random bits */
+    if (sub) r = r + 0x3Fu + fix;                   /* cpp:1314-1315 */
+  } else if (rmode == ORC_RNE) {
+    if (not_naninf) r = a + 0x3Fu + fix;            /* cpp:1250-1251 */
+  }
+  r &= 0xFFFFu;
+  if (sat) r = (r & 0x8000u) | 0x5B80u;             /* cpp:1253 */
+  if (flush) r = r & 0x8000u;                       /* cpp:1254 */
+  return (uint16_t)(r & 0xFF80u);                   /* cpp:1256 */
+}
+
+/* FP4_NEAREST: cvt_fp32_fp4_nearest_scalar cpp:1797-1824.  Works on the fp32 pattern: values are the
+ * even powers of two 2^0, 2^-2 .. 2^-12 (and 0); odd negative exponents try x*1.6 (double multiply,
+ * rounded back to float) and otherwise drop one exponent; anything with exponent > 0 (Inf / NaN too)
+ * becomes +-1. */
+static float fp4_cast(float x, float scale, float rcp) {
+  volatile float p = scale * x;                     /* cpp:1805 */
+  float f = p;
+  uint32_t u = f2u(f);
+  int exp_f = (int)((u & 0x7F800000u) >> 23) - 127;
+  uint32_t sign_f = u & 0x80000000u;
+  if (exp_f < 0 && (exp_f % 2)) {                   /* cpp:1811 */
+    f = (float)((double)f * 1.6);
+    u = f2u(f);
+  }
+  if (exp_f > 0) u = sign_f | (127u << 23);         /* cpp:1813 */
+  u &= 0xFF800000u;
+  exp_f = (int)((u & 0x7F800000u) >> 23) - 127;
+  if (exp_f < 0 && (exp_f % 2)) u = sign_f | ((uint32_t)(exp_f + 126) << 23); /* cpp:1818 */
+  if (exp_f < -12) u = 0;                           /* cpp:1821: +0, sign dropped */
+  return u2f(u) * rcp;
+}
+
 uint16_t orc_quantize_h(uint16_t h, int fmt, int rmode, uint32_t rnd) {
   switch (fmt) {
+    case ORC_FMT_E4M3_IEEE: return q_e4m3_ieee(h, rmode, rnd);
     case ORC_FMT_E5M2:     return q_e5m2(h, rmode, rnd, 0);
     case ORC_FMT_E5M2_DAZ: return q_e5m2(h, rmode, rnd, 1);
     case ORC_FMT_E4M3:     return q_e4m3_e3m4(h, rmode, rnd, 7, 0x5F00u, 8, 0x0300u, -9, -6);
@@ -235,6 +288,7 @@ float orc_cast_one(float x, int fmt, int rmode, float scale, float rcp, uint32_t
   if (fmt == ORC_FMT_BF16) return bf16_cast(x, rmode, rnd);               /* no scale: cpp:1948-1957 */
   if (fmt == ORC_FMT_FP16) return fp16_cast(x, rmode, 0, rnd);
   if (fmt == ORC_FMT_FP16_DAZ) return fp16_cast(x, rmode, 1, rnd);
+  if (fmt == ORC_FMT_FP4) return fp4_cast(x, scale, rcp);
   float p = scale * x;                                                    /* cpp:718 */
   uint16_t h = orc_f32_to_f16_rne(p);                                     /* cpp:720 */
   uint16_t q = orc_quantize_h(h, fmt, rmode, rnd);
@@ -299,6 +353,8 @@ static int valid_combo(int fmt, int rmode) {
     case ORC_FMT_BF16: return rmode == ORC_RNE || rmode == ORC_STOCHASTIC || rmode == ORC_RTZ;
     case ORC_FMT_FP16: return rmode == ORC_RNE || rmode == ORC_STOCHASTIC;
     case ORC_FMT_FP16_DAZ: return rmode == ORC_RNE;
+    case ORC_FMT_E4M3_IEEE: return rmode == ORC_RNE || rmode == ORC_STOCHASTIC;
+    case ORC_FMT_FP4: return rmode == ORC_RNE; /* "NEAREST" */
     default: return 0;
   }
 }
@@ -313,6 +369,55 @@ int orc_cast_f32(const float *in, float *out, uint64_t n, int fmt, int rmode, fl
   for (int64_t i = 0; i < nn; i++) {
     uint32_t rnd = sr ? rand_bits_v(seed, offset, elem_base + (uint64_t)i, fmt, 4u) : 0u;
     out[i] = orc_cast_one(in[i], fmt, rmode, scale, rcp, rnd);
+  }
+  return 0;
+}
+
+/* Block normalisation (E5M2_Kernel cpp:778-815, E4M3_Kernel cpp:1149-1190, E4M3_IEEE_Kernel
+ * cpp:1441-1478, E3M4_Kernel cpp:1734-1770, FP4_Nearest_Kernel cpp:1840-1860): per block of
+ * block_size elements, maxval = max |x| by a compare that never takes a NaN, p2 = maxval with the
+ * mantissa cleared, scale = 2*p2/16384 (E5M2), 2*p2/8 (E4M3, E4M3_IEEE), 2*p2 (E3M4), 1/maxval (FP4),
+ * then the ordinary cast of the block with that scale.  The caller guarantees n % block_size == 0
+ * (fpemu_forward demotes block_norm otherwise, cpp:2020-2025).  Formats without a block-norm branch
+ * in the reference (E5M2_DAZ, BFLOAT16, FLOAT16) are not accepted here.
+ * Stochastic noise: block b draws as call offset + b, element index = position in the block. */
+float orc_blocknorm_scale(float maxval, int fmt) {
+  float p2 = u2f(f2u(maxval) & 0x7F800000u);
+  volatile float s = 2.0f * p2;
+  switch (fmt) {
+    case ORC_FMT_E5M2: s = s / 16384.0f; break;
+    case ORC_FMT_E4M3: case ORC_FMT_E4M3_IEEE: s = s / 8.0f; break;
+    case ORC_FMT_E3M4: break;
+    case ORC_FMT_FP4: s = (float)(1.0 / (double)maxval); break;
+    default: break;
+  }
+  return s;
+}
+
+int orc_cast_blocknorm_f32(const float *in, float *out, uint64_t n, int fmt, int rmode,
+                           uint64_t block_size, uint64_t seed, uint64_t offset) {
+  if (!valid_combo(fmt, rmode)) return -1;
+  if (fmt != ORC_FMT_E5M2 && fmt != ORC_FMT_E4M3 && fmt != ORC_FMT_E4M3_IEEE && fmt != ORC_FMT_E3M4 &&
+      fmt != ORC_FMT_FP4)
+    return -1;
+  if (block_size == 0 || n % block_size) return -1;
+  int sr = (rmode == ORC_STOCHASTIC);
+  int64_t nb = (int64_t)(n / block_size);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < nb; b++) {
+    const float *bi = in + (uint64_t)b * block_size;
+    float *bo = out + (uint64_t)b * block_size;
+    float maxval = 0.0f;
+    for (uint64_t i = 0; i < block_size; i++) {
+      float a = fabsf(bi[i]);
+      maxval = (maxval < a) ? a : maxval;
+    }
+    float scale = orc_blocknorm_scale(maxval, fmt);
+    float rcp = orc_scale_reciprocal(scale);
+    for (uint64_t i = 0; i < block_size; i++) {
+      uint32_t rnd = sr ? rand_bits_v(seed, offset + (uint64_t)b, i, fmt, 4u) : 0u;
+      bo[i] = orc_cast_one(bi[i], fmt, rmode, scale, rcp, rnd);
+    }
   }
   return 0;
 }
@@ -404,6 +509,9 @@ int orc_parse_mode(const char *mode, int *fmt, int *rmode) {
     {"E4M3_RTZ", ORC_FMT_E4M3, ORC_RTZ},
     {"E3M4_RTZ", ORC_FMT_E3M4, ORC_RTZ},
     {"BFLOAT16_RTZ", ORC_FMT_BF16, ORC_RTZ},
+    {"E4M3_IEEE_RNE", ORC_FMT_E4M3_IEEE, ORC_RNE},     /* cpp:1958 */
+    {"E4M3_IEEE_STOCHASTIC", ORC_FMT_E4M3_IEEE, ORC_STOCHASTIC},
+    {"FP4_NEAREST", ORC_FMT_FP4, ORC_RNE},             /* cpp:1994 */
   };
   for (unsigned i = 0; i < sizeof(tab) / sizeof(tab[0]); i++) {
     if (strcmp(mode, tab[i].name) == 0) {
@@ -426,10 +534,13 @@ int orc_num_threads(void) {
 /* ------------------------------------------------------------------------------------------
  * cmodel emulated GEMM: simple_sgemm_impl (mpemu/cmodel/simple/simple_gemm_impl.cpp:71-237) with
  * MMEngine_avx2_ps (simple_mm_engine.cpp:13-27), called as simple_gemm does (simple_gemm.cpp:45-67,
- * beta = 0).  Per output element: acc = +0; for k ascending: acc = fp32(acc + fp32(a*b)) -- separate
- * vmulps / vaddps, no FMA -- then C += alpha*acc + beta*C (impl.cpp:226-231).  The reference's
- * zero padding of K to a multiple of 64 adds +0 to a chain that is never -0: a no-op.
- * fused != 0 models the MFMA fp32-accumulate variant instead: acc = fmaf(a, b, acc).
+ * beta = 0).  Per output element: acc = +0; for k ascending the engine's add(acc, mul(a, b)); then
+ * C += alpha*acc + beta*C (impl.cpp:226-231).  The reference's zero padding of K to a multiple of 64
+ * adds +0 to a chain that is never -0: a no-op.
+ * fused == 0: acc = fp32(acc + fp32(a*b)), separate vmulps / vaddps -- the sources compiled for a host
+ *             without FMA (oracle/build_ref.py nofma=True);
+ * fused != 0: acc = fmaf(a, b, acc) -- the sources compiled with the reference's own flags on an FMA
+ *             host (g++ contracts the intrinsics pair into vfmadd231ps).  Both pinned by gemm.npz.
  * Row-major; op(A) = A[M][K] or, a_trans, A[K][M]; op(B) = B[K][N] or, b_trans, B[N][K].
  * ---------------------------------------------------------------------------------------- */
 void orc_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,

@@ -27,7 +27,9 @@ enum {
   ORC_FMT_BF16 = 3,     /* cpp/fpemu_impl.cpp:207-232 (RNE, canonical), :284-329 (SR) */
   ORC_FMT_FP16 = 4,     /* cpp/fpemu_impl.cpp:356-423  FLOAT16_Kernel */
   ORC_FMT_E5M2_DAZ = 5, /* cpp/fpemu_impl.cpp:846-919  E5M2_DAZ_Kernel */
-  ORC_FMT_FP16_DAZ = 6  /* FLOAT16_Kernel with no_denorm=1 (:374-377) */
+  ORC_FMT_FP16_DAZ = 6, /* FLOAT16_Kernel with no_denorm=1 (:374-377) */
+  ORC_FMT_E4M3_IEEE = 7,/* cpp/fpemu_impl.cpp:1213-1328 (AVX-512 routines: canonical, see .c) */
+  ORC_FMT_FP4 = 8       /* cpp/fpemu_impl.cpp:1797-1824 cvt_fp32_fp4_nearest_scalar */
 };
 
 /* Rounding-mode ids: the reference's own enum, cpp/fpemu_impl.cpp:15-23. */
@@ -72,6 +74,13 @@ uint32_t orc_rand_bits(uint64_t seed, uint64_t offset, uint64_t idx, int fmt);
 int orc_cast_f32(const float *in, float *out, uint64_t n, int fmt, int rmode, float scale,
                  uint64_t seed, uint64_t offset, uint64_t elem_base);
 
+/* Block-normalised cast (block_norm = true of the pybind forward): per block of block_size elements
+ * the scale is derived from the block's max |x| (formulas in the .c), then the ordinary cast.
+ * n % block_size must be 0.  Returns 0 / -1. */
+float orc_blocknorm_scale(float maxval, int fmt);
+int orc_cast_blocknorm_f32(const float *in, float *out, uint64_t n, int fmt, int rmode,
+                           uint64_t block_size, uint64_t seed, uint64_t offset);
+
 /* 16-bit storage variants: up-convert (exact), canonical fp32 algorithm, RNE down-convert
  * (SURVEY section 8(a) "Non-fp32 inputs").  is_bf16 selects bf16 vs fp16 storage. */
 int orc_cast_16(const uint16_t *in, uint16_t *out, uint64_t n, int is_bf16, int fmt, int rmode,
@@ -96,8 +105,9 @@ void orc_build_lut(int fmt, int rmode, uint16_t *lut);
 int orc_parse_mode(const char *mode, int *fmt, int *rmode);
 
 /* cmodel emulated GEMM (reference simple_gemm_impl.cpp:71-237, simple_mm_engine.cpp:13-27): per
- * element a k-ascending fp32 chain of separate multiply and add; fused != 0: fmaf chain (the model of
- * the MFMA fp32-accumulate variant).  C accumulates: C += alpha*acc + 0*C. */
+ * element a k-ascending fp32 chain; fused == 0: separate multiply and add (reference built without
+ * FMA); fused != 0: fmaf chain (reference built with its own flags on an FMA host).
+ * C accumulates: C += alpha*acc + 0*C. */
 void orc_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
                   int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans,
                   int fused);

@@ -12,7 +12,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libfpemu_oracle.so")
 
-FMT = {"E5M2": 0, "E4M3": 1, "E3M4": 2, "BF16": 3, "FP16": 4, "E5M2_DAZ": 5, "FP16_DAZ": 6}
+FMT = {"E5M2": 0, "E4M3": 1, "E3M4": 2, "BF16": 3, "FP16": 4, "E5M2_DAZ": 5, "FP16_DAZ": 6,
+       "E4M3_IEEE": 7, "FP4": 8}
 RMODE = {"RTZ": 0, "RNE": 1, "STOCHASTIC": 2, "RNAZ": 3, "RNTZ": 4, "RPINF": 5, "RNINF": 6}
 
 _lib = None
@@ -60,6 +61,10 @@ def lib():
     L.orc_build_lut.argtypes = [i32, i32, vp]
     L.orc_parse_mode.restype = i32
     L.orc_parse_mode.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.orc_blocknorm_scale.restype = f32
+    L.orc_blocknorm_scale.argtypes = [f32, i32]
+    L.orc_cast_blocknorm_f32.restype = i32
+    L.orc_cast_blocknorm_f32.argtypes = [vp, vp, u64, i32, i32, u64, u64, u64]
     i64 = ctypes.c_int64
     L.orc_gemm_f32.restype = None
     L.orc_gemm_f32.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, i32, i32, i32]
@@ -89,6 +94,17 @@ def cast(x, mode, scale=1.0, seed=0, offset=0, elem_base=0, out=None):
                             elem_base)
     if rc != 0:
         raise ValueError("oracle: invalid fmt/rmode for %r" % (mode,))
+    return y
+
+
+def cast_blocknorm(x, mode, block_size, seed=0, offset=0):
+    """Oracle of forward(..., block_norm=True, block_size) on a float32 array; size % block_size == 0."""
+    fmt, rmode = parse_mode(mode)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    rc = lib().orc_cast_blocknorm_f32(_ptr(x), _ptr(y), x.size, fmt, rmode, block_size, seed, offset)
+    if rc != 0:
+        raise ValueError("oracle: block norm not defined for %r / block_size %d" % (mode, block_size))
     return y
 
 

@@ -14,7 +14,11 @@ DET_MODES = ["E5M2_RNE", "E4M3_RNE", "E3M4_RNE", "E5M2_RTZ", "E5M2_RNAZ", "E5M2_
 EXT_MODES = ["E4M3_RTZ", "E3M4_RTZ", "BFLOAT16_RTZ"]  # not defined by the reference: parity unpinned
 SR_MODES = ["E5M2_STOCHASTIC", "E4M3_STOCHASTIC", "E3M4_STOCHASTIC", "BFLOAT16_STOCHASTIC",
             "FLOAT16_STOCHASTIC", "E5M2_DAZ_STOCHASTIC"]
-ALL_MODES = DET_MODES + EXT_MODES + SR_MODES
+# pinned by tests/golden/ext2.npz (E4M3_IEEE: the reference's AVX-512 routines)
+F4_MODES = ["E4M3_IEEE_RNE", "FP4_NEAREST"]
+F4_SR_MODES = ["E4M3_IEEE_STOCHASTIC"]
+BLOCKNORM_MODES = ["E5M2_RNE", "E5M2_RTZ", "E5M2_RNAZ", "E4M3_RNE", "E3M4_RNE", "E4M3_IEEE_RNE", "FP4_NEAREST"]
+ALL_MODES = DET_MODES + EXT_MODES + SR_MODES + F4_MODES + F4_SR_MODES
 
 
 def npz(name):

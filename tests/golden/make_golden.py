@@ -18,6 +18,8 @@ Fixtures (all loadable with numpy.load(allow_pickle=False) / json):
   qtensor.npz     reference qutils.quantize_tensor (per-tensor / per-channel / fine-grained / mean)
   models.npz      reference mpt_emu.quantize_model / scale_shift on tiny seeded models
   gemm.npz        reference cmodel simple_gemm_dev.gemm, FMA build and -mno-fma build
+  ext2.npz        E4M3_IEEE_RNE (AVX-512 routine = canonical), FP4_NEAREST, block_norm=True outputs,
+                  E4M3_IEEE_STOCHASTIC round-up counts
 """
 import json
 import os
@@ -242,6 +244,71 @@ def gen_gemm():
     np.savez_compressed(os.path.join(HERE, "gemm.npz"), **out)
 
 
+def ref_blocknorm(mod, x, mode, bs):
+    t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32).copy())
+    return mod.forward(t, mode, t.numel(), False, 1.0, True, int(bs))[0].numpy().view(np.uint32).copy()
+
+
+def gen_ext2():
+    out = {}
+    h = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    out["lut/E4M3_IEEE_RNE"] = ref_cast(NAT, h, "E4M3_IEEE_RNE")
+    out["lut/FP4_NEAREST"] = ref_cast(SCA, h, "FP4_NEAREST")
+    rng = np.random.default_rng(424242)
+    raw = rng.integers(0, 2 ** 32, size=8192, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    x = np.concatenate([raw, lognormal(rng, 8192)])
+    x[8192 + 128:8192 + 192] = 0.0          # all-zero blocks (scale 0 -> 0 * inf)
+    x[8192 + 300] = 0.0
+    x[8192 + 301] = -0.0
+    x[8192 + 512:8192 + 576] = np.float32(1e-41) * np.arange(64, dtype=np.float32)  # denormal maxima
+    out["input_bits"] = x.view(np.uint32)
+    for i, sc in enumerate((1.0, 0.37, 37.5)):
+        out["raw/E4M3_IEEE_RNE/%d" % i] = ref_cast(NAT, x, "E4M3_IEEE_RNE", np.float32(sc))
+        out["raw/FP4_NEAREST/%d" % i] = ref_cast(SCA, x, "FP4_NEAREST", np.float32(sc))
+    out["raw_scales"] = np.array([1.0, 0.37, 37.5], dtype=np.float32)
+    # block_norm=True.  E4M3_IEEE only with block sizes % 32 == 0 on the native build (other sizes run
+    # its scalar routine, whose saturation test is wrong); the rest on the scalar build.
+    cases = []
+    for mode, mod, sizes in (("E5M2_RNE", SCA, (1, 8, 32, 64, 4096, 16384)), ("E5M2_RTZ", SCA, (8, 64)),
+                             ("E5M2_RNAZ", SCA, (64,)), ("E4M3_RNE", SCA, (1, 8, 32, 64, 4096, 16384)),
+                             ("E3M4_RNE", SCA, (1, 8, 32, 64, 4096, 16384)),
+                             ("FP4_NEAREST", SCA, (8, 32, 64, 4096, 16384)),
+                             ("E4M3_IEEE_RNE", NAT, (32, 64, 4096, 16384))):
+        for bs in sizes:
+            out["bn/%s/%d" % (mode, bs)] = ref_blocknorm(mod, x, mode, bs)
+            cases.append("%s/%d" % (mode, bs))
+    x24 = x[4096:4096 + 6144]
+    for mode in ("E5M2_RNE", "E4M3_RNE", "E3M4_RNE", "FP4_NEAREST"):
+        out["bn24/%s" % mode] = ref_blocknorm(SCA, x24, mode, 24)
+    out["bn_cases"] = np.array(cases)
+    # a block_size that does not divide size: the reference demotes block_norm (cpp:2020-2025)
+    out["bn_demoted/E4M3_RNE/100"] = ref_blocknorm(SCA, x, "E4M3_RNE", 100)
+    # E4M3_IEEE_STOCHASTIC round-up counts, AVX-512 routine (N % 32 == 0)
+    N = 1 << 16
+    k = 7
+    xb, lob, hib, nlo, nhi = [], [], [], [], []
+    base = 0x3C00 | (1 << k)
+    for r in range(0, 1 << k, 4):
+        xv = np.array([base | r], dtype=np.uint16).view(np.float16).astype(np.float32)[0]
+        lo = np.array([base], dtype=np.uint16).view(np.float16).astype(np.float32)[0]
+        hi = np.array([base + (1 << k)], dtype=np.uint16).view(np.float16).astype(np.float32)[0]
+        o = ref_cast(NAT, np.full(N, xv, dtype=np.float32), "E4M3_IEEE_STOCHASTIC").view(np.float32)
+        xb.append(np.float32(xv).view(np.uint32)); lob.append(np.float32(lo).view(np.uint32))
+        hib.append(np.float32(hi).view(np.uint32))
+        nlo.append(int((o == lo).sum())); nhi.append(int((o == hi).sum()))
+    # pseudo-subnormal range rounds RNE under STOCHASTIC (cpp:1314): deterministic
+    sub = np.array([0.005, 0.0051, 0.0107, 0.0137, 0.0029296875, 0.0021], dtype=np.float32)
+    out["sr/sub_in"] = sub.view(np.uint32)
+    out["sr/sub_out"] = ref_cast(NAT, np.tile(sub, 32)[:192], "E4M3_IEEE_STOCHASTIC")[:6]
+    out["sr/x_bits"] = np.array(xb, dtype=np.uint32)
+    out["sr/lo_bits"] = np.array(lob, dtype=np.uint32)
+    out["sr/hi_bits"] = np.array(hib, dtype=np.uint32)
+    out["sr/n_lo"] = np.array(nlo, dtype=np.int64)
+    out["sr/n_hi"] = np.array(nhi, dtype=np.int64)
+    out["sr/N"] = np.array([N], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "ext2.npz"), **out)
+
+
 def _tiny_models():
     torch.manual_seed(1234)
     mlp = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.ReLU(), torch.nn.Linear(64, 24))
@@ -313,7 +380,7 @@ def gen_models():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor", "models", "gemm"]
+    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor", "models", "gemm", "ext2"]
     for w in which:
         globals()["gen_" + w]()
         print("golden:", w, "done")

@@ -44,9 +44,7 @@ def test_mode_table_matches_oracle():
         b.parse_mode("E4M3_FOO")
     with pytest.raises(ValueError):
         b.parse_mode("")
-    for m in ("E4M3_IEEE_RNE", "E4M3_IEEE_STOCHASTIC", "FP4_NEAREST"):
-        with pytest.raises(NotImplementedError):
-            b.parse_mode(m)
+    assert b.parse_mode("E4M3_IEEE_RNE") == (7, 1) and b.parse_mode("FP4_NEAREST") == (8, 1)
 
 
 def test_argument_errors_without_gpu():
@@ -58,11 +56,18 @@ def test_argument_errors_without_gpu():
     assert b"null" in L.fpemu_last_error()
     assert L.fpemu_cast(16, 16, 16, 7, 1, 1, 1.0, 0, 0, 0, None) == -1           # bad dtype
     assert L.fpemu_cast(16, 16, 16, 0, 1, 5, 1.0, 0, 0, 0, None) == -1           # E4M3_RPINF undefined
+    assert L.fpemu_quantize_blocks(16, 16, 100, 7, 0, 1, 1, 0, 0, None) == -1    # 100 % 7 != 0
+    assert L.fpemu_quantize_blocks(16, 16, 64, 8, 0, 3, 1, 0, 0, None) == -1     # BF16 has no block norm
+    assert L.fpemu_quantize_blocks(16, 16, 64, 8, 0, 5, 1, 0, 0, None) == -1     # nor E5M2_DAZ
+    assert L.fpemu_gemm_f32(None, 16, 16, 4, 4, 4, 4, 4, 4, 1.0, 0, 0, 1, None) == -1
+    assert L.fpemu_gemm_f32(16, 16, 16, 4, 4, 4, 4, 4, 4, 1.0, 0, 0, 9, None) == -1   # unknown variant
+    assert L.fpemu_gemm_f32(18, 16, 16, 4, 4, 4, 4, 4, 4, 1.0, 0, 0, 1, None) == -4   # misaligned C
     assert L.fpemu_cast(18, 18, 16, 0, 1, 1, 1.0, 0, 0, 0, None) == -4           # misaligned fp32
     assert L.fpemu_cast(16, 16, 16, 0, 1, 1, float("inf"), 0, 0, 0, None) == -1  # cpp:772-776
     assert L.fpemu_cast(16, 16, 0, 0, 1, 1, 1.0, 0, 0, 0, None) == 0             # empty: no launch
     assert L.fpemu_forward(16, 16, 0, b"NOPE", 16, 1.0, 0, 1, 0, 0, None) == -2
-    assert L.fpemu_forward(16, 16, 0, b"E4M3_RNE", 16, 1.0, 1, 4, 0, 0, None) == -3  # block_norm
+    assert L.fpemu_forward(None, None, 0, b"E4M3_RNE", 16, 1.0, 1, 4, 0, 0, None) == -1  # block_norm: null buffers
+    assert b"quantize_blocks" in L.fpemu_last_error()
     assert L.fpemu_amax(None, 4, 0, None, None) == -1
     assert L.fpemu_amax(16, 0, 0, 16, None) == 0
     assert L.fpemu_cast_scaled(16, 16, 4, 0, 1, 1, None, 448.0, 1, 0, 0, 0, None) == -1

@@ -152,8 +152,8 @@ def test_forward_signature_and_errors(hip):
     assert_bits_equal(xi.cpu().numpy(), orc.cast(x.cpu().numpy(), "E5M2_RNE"))
     with pytest.raises(ValueError):
         hip.forward(x, "E4M3_BOGUS", x.numel(), False, 1.0, False, 1)
-    with pytest.raises(NotImplementedError):
-        hip.forward(x, "E4M3_RNE", x.numel(), False, 1.0, True, 8)
+    out = hip.forward(x, "E4M3_RNE", x.numel(), False, 1.0, True, 8)   # block norm (tests/test_gpu_ext2.py)
+    assert_bits_equal(out[0].cpu().numpy(), orc.cast_blocknorm(x.cpu().numpy(), "E4M3_RNE", 8), nan_payload_ok=True)
     # size % block_size != 0 demotes block_norm (cpp:2020-2025) and the plain cast runs
     out = hip.forward(x, "E4M3_RNE", x.numel(), False, 1.0, True, 7)
     assert_bits_equal(out[0].cpu().numpy(), orc.cast(x.cpu().numpy(), "E4M3_RNE"))

@@ -247,3 +247,63 @@ def test_gemm_oracle_matches_reference_builds(build, fused):
         got = orc.gemm(A, B, 0.75, bool(at), bool(bt), out=c0.copy(), fused=fused)
         assert_bits_equal(got, g["Cacc/%s/%s" % (build, key)], "%s %s acc" % (build, key))
     assert n >= 40
+
+
+# ------------------------------------------------------------------------------------------
+# E4M3_IEEE, FP4_NEAREST, block norm -- tests/golden/ext2.npz
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["E4M3_IEEE_RNE", "FP4_NEAREST"])
+def test_ext2_lut_and_raw(mode):
+    g = npz("ext2.npz")
+    h = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    assert_bits_equal(orc.cast(h, mode), g["lut/" + mode], mode + " lut", nan_payload_ok=True)
+    x = g["input_bits"].view(np.float32)
+    for i, sc in enumerate(g["raw_scales"]):
+        assert_bits_equal(orc.cast(x, mode, scale=sc), g["raw/%s/%d" % (mode, i)], "%s scale %r" % (mode, sc),
+                          nan_payload_ok=True)
+
+
+def test_ext2_e4m3_ieee_limits():
+    """Max 240, NaN / Inf saturate, [2^-10, 2^-9) flushes; the scalar routine's 15.0 bug is not restated."""
+    x = np.array([14.0, 15.0, 16.0, 100.0, 239.0, 240.0, 248.0, 1e5, np.inf, -np.inf, np.nan, 2.0 ** -9,
+                  2.0 ** -10, 1.5 * 2.0 ** -10], dtype=np.float32)
+    want = np.array([14.0, 15.0, 16.0, 96.0, 240.0, 240.0, 240.0, 240.0, 240.0, -240.0, 240.0, 2.0 ** -9, 0.0, 0.0],
+                    dtype=np.float32)
+    got = orc.cast(x, "E4M3_IEEE_RNE")
+    assert np.array_equal(np.abs(got), np.abs(want)) and got[9] == -240.0
+
+
+def test_ext2_blocknorm():
+    g = npz("ext2.npz")
+    x = g["input_bits"].view(np.float32)
+    for case in g["bn_cases"]:
+        mode, bs = str(case).split("/")
+        assert_bits_equal(orc.cast_blocknorm(x, mode, int(bs)), g["bn/" + str(case)], "bn " + str(case),
+                          nan_payload_ok=True)
+    x24 = x[4096:4096 + 6144]
+    for mode in ("E5M2_RNE", "E4M3_RNE", "E3M4_RNE", "FP4_NEAREST"):
+        assert_bits_equal(orc.cast_blocknorm(x24, mode, 24), g["bn24/" + mode], "bn24 " + mode, nan_payload_ok=True)
+    # size % block_size != 0: the reference demotes to the plain cast (cpp:2020-2025)
+    assert_bits_equal(orc.cast(x, "E4M3_RNE"), g["bn_demoted/E4M3_RNE/100"], "demoted", nan_payload_ok=True)
+    with pytest.raises(ValueError):
+        orc.cast_blocknorm(x, "E4M3_RNE", 100)
+    with pytest.raises(ValueError):
+        orc.cast_blocknorm(x, "BFLOAT16_RNE", 64)
+
+
+def test_ext2_e4m3_ieee_stochastic_statistics():
+    """Oracle (Philox noise) vs the reference's AVX-512 stochastic routine (its own RNG): round-up
+    counts agree within binomial noise; pseudo-subnormals round RNE, bit-exact."""
+    g = npz("ext2.npz")
+    N = int(g["sr/N"][0])
+    for xb, lo, hi, n_hi in zip(g["sr/x_bits"], g["sr/lo_bits"], g["sr/hi_bits"], g["sr/n_hi"]):
+        x = np.full(N, np.array([xb], dtype=np.uint32).view(np.float32)[0], dtype=np.float32)
+        out = bits(orc.cast(x, "E4M3_IEEE_STOCHASTIC", seed=11, offset=int(xb) & 0xFFFF))
+        assert np.all((out == lo) | (out == hi))
+        ours = int((out == hi).sum())
+        p = ((int(xb) >> 13) & 0x7F) / 128.0
+        sigma = math.sqrt(max(N * p * (1 - p), 1.0))
+        assert abs(ours - N * p) < 5 * sigma, (hex(xb), ours, N * p)
+        assert abs(int(n_hi) - N * p) < 5 * sigma, (hex(xb), int(n_hi), N * p)
+    sub = g["sr/sub_in"].view(np.float32)
+    assert_bits_equal(orc.cast(sub, "E4M3_IEEE_STOCHASTIC", seed=3), g["sr/sub_out"], "sub-range RNE under SR")

@@ -1,0 +1,38 @@
+"""Time the cmodel GEMM kernels (both variants) on the GPU: TFLOP/s vs their rooflines."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fp8-emulation-toolkit_amd"))
+from mpemu.pytquant.hip import _binding as hip  # noqa: E402
+
+PEAK = {1: 157.3, 0: 78.6}
+
+
+def run(M, N, K, at, bt, variant, iters=5):
+    A = torch.randn((K, M) if at else (M, K), device="cuda")
+    B = torch.randn((N, K) if bt else (K, N), device="cuda")
+    C = torch.zeros(M, N, device="cuda")
+    hip.gemm_(C, A, B, 1.0, at, bt, variant)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        hip.gemm_(C, A, B, 1.0, at, bt, variant)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * M * N * K / ms / 1e9
+    print("variant=%d %5dx%5dx%5d at=%d bt=%d  %8.3f ms  %7.2f TFLOP/s  frac=%.3f" % (
+        variant, M, N, K, at, bt, ms, tf, tf / PEAK[variant]), flush=True)
+
+
+if __name__ == "__main__":
+    sizes = [(4096, 4096, 4096), (8192, 8192, 8192)]
+    if len(sys.argv) > 1:
+        sizes = [tuple(int(v) for v in s.split("x")) for s in sys.argv[1:]]
+    for v in (1, 0):
+        for (M, N, K) in sizes:
+            for at, bt in ((False, False), (False, True), (True, False), (True, True)):
+                run(M, N, K, at, bt, v)
