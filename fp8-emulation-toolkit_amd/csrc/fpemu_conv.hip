@@ -1,0 +1,323 @@
+// fpemu_conv.hip -- the cmodel "simple" direct convolution (forward, backward-data, weight-update) for
+// MI355X (gfx950).
+//
+// Replaces the reference's CPU cmodel convolution
+//   simple_conv2d_impl_{fp,bp,wu}   mpemu/cmodel/simple/simple_conv2d_impl.cpp:677-977
+//   gemm_kernel_conv_{fp,bp,wu}     mpemu/cmodel/simple/simple_conv2d_impl.cpp:372-675
+//   MMEngine_(strideB_)avx2_ps      mpemu/cmodel/simple/simple_mm_engine.cpp:13-44
+// whose numerical contract is the accumulation chain of each result element (serial execution order
+// of the reference; its OpenMP loops race on shared results, so only that order is defined):
+//   fp: out[n][k][oj][oi] = bias[k]; for cb, kj, ki, c2 : += w[k][cb*CB+c2][kj][ki] * x_padded
+//   bp: gin[n][c][y][x]   = +0;      for ob, oj asc (kj = y+pad-oj*s), ki asc (oi = (x+pad-ki)/s), o2 :
+//                                         += w[ob*KB+o2][c][kj][ki] * gout[n][ob*KB+o2][oj][oi]
+//   wu: gw[k][c][kj][ki]  = +0;      for n, oj, oi : += gout[n][k][oj][oi] * x_padded[n][c][oj*s+kj][oi*s+ki]
+// (CB / KB = 64-channel blocks, the whole dimension when it is < 64).  Each is a k-ordered chain, so
+// each is ONE chain-mode GEMM (fpemu_gemm_chain_f32: accumulators start at C, fmaf chain on the fp32
+// MFMA or separate roundings on the VALU, C = acc) over operands laid out in that order:
+//   fp: out[n]  (K x P)      = chain(bias rows;  Wfp (K x CRS)    @ cols[n]  (CRS x P))     batched over n
+//   bp: gin[n]  (C x HW)     = chain(0;          Wbp (C x KRS)    @ colsb[n] (KRS x HW))    batched over n
+//   wu: Gw      (K x CRS)    = chain(Gw;         gout[n] (K x P)  @ cols[n]^T (P x CRS))    n = 0, 1, ...
+// cols / colsb are gathered by the kernels below (zero for padding taps: the reference multiplies its
+// zero padding in as well; for bp taps that do not exist for a pixel contribute w * 0, which leaves a
+// chain that started at +0 unchanged for every finite w).  Everything here is HBM-bound gather work;
+// the flops are in fpemu_gemm.hip.
+//
+// Reference defects NOT reproduced: with C < 64 (or K < 64) and N > 1 the reference's
+// packing routines index images with C/64 = 0 and collapse the batch (:154, :242); here every image is
+// convolved, which equals the reference run one image at a time.  C or K > 64 and not a multiple of
+// 64 makes the reference drop channels / read out of bounds (:143-160, :282-307): rejected here.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/fpemu_hip.h"
+
+extern "C" void fpemu_set_error_(const char *msg);
+
+namespace {
+
+constexpr int NT = 256;
+
+struct Geo {
+  int64_t N, C, H, W, K, R, S, stride, pad, OH, OW, CB, KB;
+};
+
+__device__ __forceinline__ int64_t gtid() { return (int64_t)blockIdx.x * NT + threadIdx.x; }
+__device__ __forceinline__ int64_t gstride() { return (int64_t)gridDim.x * NT; }
+
+// Wfp[k][(cb, kj, ki, c2)] = w[k][cb*CB + c2][kj][ki]
+__global__ __launch_bounds__(NT) void pack_w_fp(const float *__restrict__ w, float *__restrict__ Wm, Geo g) {
+  const int64_t crs = g.C * g.R * g.S, total = g.K * crs;
+  for (int64_t i = gtid(); i < total; i += gstride()) {
+    const int64_t k = i / crs;
+    int64_t kk = i % crs;
+    const int64_t c2 = kk % g.CB; kk /= g.CB;
+    const int64_t ki = kk % g.S; kk /= g.S;
+    const int64_t kj = kk % g.R;
+    const int64_t cb = kk / g.R;
+    Wm[i] = w[((k * g.C + cb * g.CB + c2) * g.R + kj) * g.S + ki];
+  }
+}
+
+// gw[k][c][kj][ki] = Gw[k][(cb, kj, ki, c2)]
+__global__ __launch_bounds__(NT) void unpack_gw(const float *__restrict__ Gm, float *__restrict__ gw, Geo g) {
+  const int64_t crs = g.C * g.R * g.S, total = g.K * crs;
+  for (int64_t i = gtid(); i < total; i += gstride()) {
+    const int64_t k = i / crs;
+    int64_t kk = i % crs;
+    const int64_t c2 = kk % g.CB; kk /= g.CB;
+    const int64_t ki = kk % g.S; kk /= g.S;
+    const int64_t kj = kk % g.R;
+    const int64_t cb = kk / g.R;
+    gw[((k * g.C + cb * g.CB + c2) * g.R + kj) * g.S + ki] = Gm[i];
+  }
+}
+
+// Wbp[c][(ob, tj, ti, o2)] = w[ob*KB + o2][c][R-1-tj][ti]      (oj ascending = kj descending)
+__global__ __launch_bounds__(NT) void pack_w_bp(const float *__restrict__ w, float *__restrict__ Wm, Geo g) {
+  const int64_t krs = g.K * g.R * g.S, total = g.C * krs;
+  for (int64_t i = gtid(); i < total; i += gstride()) {
+    const int64_t c = i / krs;
+    int64_t kk = i % krs;
+    const int64_t o2 = kk % g.KB; kk /= g.KB;
+    const int64_t ti = kk % g.S; kk /= g.S;
+    const int64_t tj = kk % g.R;
+    const int64_t ob = kk / g.R;
+    Wm[i] = w[(((ob * g.KB + o2) * g.C + c) * g.R + (g.R - 1 - tj)) * g.S + ti];
+  }
+}
+
+// cols[n][(cb, kj, ki, c2)][(oj, oi)] = x[n0 + n][cb*CB + c2][oj*s + kj - pad][oi*s + ki - pad], 0 outside
+__global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float *__restrict__ cols, Geo g,
+                                              int64_t nimg) {
+  const int64_t P = g.OH * g.OW, crs = g.C * g.R * g.S, total = nimg * crs * P;
+  for (int64_t i = gtid(); i < total; i += gstride()) {
+    const int64_t p = i % P;
+    int64_t kk = (i / P) % crs;
+    const int64_t n = i / (P * crs);
+    const int64_t c2 = kk % g.CB; kk /= g.CB;
+    const int64_t ki = kk % g.S; kk /= g.S;
+    const int64_t kj = kk % g.R;
+    const int64_t cb = kk / g.R;
+    const int64_t oj = p / g.OW, oi = p % g.OW;
+    const int64_t y = oj * g.stride + kj - g.pad, xx = oi * g.stride + ki - g.pad;
+    float v = 0.f;
+    if (y >= 0 && y < g.H && xx >= 0 && xx < g.W) v = x[((n * g.C + cb * g.CB + c2) * g.H + y) * g.W + xx];
+    cols[i] = v;
+  }
+}
+
+// colsb[n][(ob, tj, ti, o2)][(ih, iw)] = gout[n][ob*KB + o2][oj][oi] with kj = R-1-tj, ki = ti,
+// oj = (ih + pad - kj)/s, oi = (iw + pad - ki)/s when those divide and are in range, else 0
+__global__ __launch_bounds__(NT) void cols_bp(const float *__restrict__ go, float *__restrict__ cols, Geo g,
+                                              int64_t nimg) {
+  const int64_t HW = g.H * g.W, krs = g.K * g.R * g.S, total = nimg * krs * HW, P = g.OH * g.OW;
+  for (int64_t i = gtid(); i < total; i += gstride()) {
+    const int64_t pix = i % HW;
+    int64_t kk = (i / HW) % krs;
+    const int64_t n = i / (HW * krs);
+    const int64_t o2 = kk % g.KB; kk /= g.KB;
+    const int64_t ti = kk % g.S; kk /= g.S;
+    const int64_t tj = kk % g.R;
+    const int64_t ob = kk / g.R;
+    const int64_t dy = pix / g.W + g.pad - (g.R - 1 - tj), dx = pix % g.W + g.pad - ti;
+    float v = 0.f;
+    if (dy >= 0 && dx >= 0 && dy % g.stride == 0 && dx % g.stride == 0) {
+      const int64_t oj = dy / g.stride, oi = dx / g.stride;
+      if (oj < g.OH && oi < g.OW) v = go[(n * g.K + ob * g.KB + o2) * P + oj * g.OW + oi];
+    }
+    cols[i] = v;
+  }
+}
+
+// out[n][k][p] = bias[k] (+0 when channel padding exists in the reference: turns a -0 bias into +0), or 0
+__global__ __launch_bounds__(NT) void fill_rows(float *__restrict__ out, const float *__restrict__ bias,
+                                                int64_t rows_per_img, int64_t P, int64_t total, int add_zero) {
+  for (int64_t i = gtid(); i < total; i += gstride()) {
+    float b = 0.f;
+    if (bias != nullptr) {
+      b = bias[(i / P) % rows_per_img];
+      if (add_zero) b = b + 0.0f;
+    }
+    out[i] = b;
+  }
+}
+
+unsigned blocks_for(int64_t total) {
+  int64_t b = (total + NT - 1) / NT;
+  if (b > 1048576) b = 1048576;
+  return b < 1 ? 1u : (unsigned)b;
+}
+
+int fail(const char *who, int code, const char *what) {
+  char msg[200];
+  snprintf(msg, sizeof(msg), "%s: %s", who, what);
+  fpemu_set_error_(msg);
+  return code;
+}
+
+int make_geo(const char *who, Geo &g, int64_t N, int64_t C, int64_t H, int64_t W, int64_t K, int64_t R,
+             int64_t S, int64_t stride, int64_t pad) {
+  if (N < 0 || C < 1 || H < 1 || W < 1 || K < 1 || R < 1 || S < 1 || stride < 1 || pad < 0)
+    return fail(who, FPEMU_EINVAL, "bad dimension");
+  if (H + 2 * pad < R || W + 2 * pad < S) return fail(who, FPEMU_EINVAL, "filter larger than the padded input");
+  if ((C > 64 && C % 64) || (K > 64 && K % 64))
+    return fail(who, FPEMU_EINVAL,
+                "C and K must each be <= 64 or a multiple of 64 (the reference's 64-channel packing is undefined otherwise)");
+  g.N = N; g.C = C; g.H = H; g.W = W; g.K = K; g.R = R; g.S = S; g.stride = stride; g.pad = pad;
+  g.OH = (H + 2 * pad - R) / stride + 1;
+  g.OW = (W + 2 * pad - S) / stride + 1;
+  g.CB = C < 64 ? C : 64;
+  g.KB = K < 64 ? K : 64;
+  if (C * R * S > 0x7FFFFFFF || K * R * S > 0x7FFFFFFF || g.OH * g.OW > 0x7FFFFFFF || H * W > 0x7FFFFFFF)
+    return fail(who, FPEMU_EINVAL, "dimension out of range");
+  return FPEMU_OK;
+}
+
+// floats: packed weights (or the packed gradient) + the gathered operand of `chunk` images
+constexpr int64_t kColsCapFloats = (int64_t)1 << 30;  // 4 GiB of gathered operand per chunk at most
+
+void ws_layout(int kind, const Geo &g, int64_t &w_floats, int64_t &per_img) {
+  if (kind == FPEMU_CONV_BP) {
+    w_floats = g.C * g.K * g.R * g.S;
+    per_img = g.K * g.R * g.S * g.H * g.W;
+  } else {
+    w_floats = g.K * g.C * g.R * g.S;
+    per_img = g.C * g.R * g.S * g.OH * g.OW;
+  }
+  w_floats = (w_floats + 63) & ~(int64_t)63;  // keep the gathered operand 256-byte aligned
+}
+
+int64_t chunk_images(const Geo &g, int64_t per_img, int64_t avail_floats) {
+  int64_t c = avail_floats / (per_img > 0 ? per_img : 1);
+  if (c > g.N) c = g.N;
+  if (c > 65535) c = 65535;  // grid.y
+  return c;
+}
+
+#define CHECK_LAUNCH(who)                                               \
+  do {                                                                  \
+    hipError_t e_ = hipGetLastError();                                  \
+    if (e_ != hipSuccess) return fail(who, (int)e_, hipGetErrorString(e_)); \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int fpemu_gemm_chain_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                         int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans, int variant,
+                         int64_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, void *stream);
+
+uint64_t fpemu_conv2d_workspace_bytes(int kind, int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
+                                      int64_t R, int64_t S, int64_t stride, int64_t pad) {
+  Geo g;
+  if (kind < FPEMU_CONV_FP || kind > FPEMU_CONV_WU) return 0;
+  if (make_geo("fpemu_conv2d_workspace_bytes", g, N, C, H, W, K, R, S, stride, pad) != FPEMU_OK) return 0;
+  int64_t wf, per;
+  ws_layout(kind, g, wf, per);
+  int64_t imgs = per > 0 ? kColsCapFloats / per : N;
+  if (imgs < 1) imgs = 1;
+  if (imgs > N) imgs = N;
+  return (uint64_t)(wf + imgs * per) * 4u;
+}
+
+int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float *bias, int64_t N, int64_t C,
+                        int64_t H, int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                        int variant, void *ws, uint64_t ws_bytes, void *stream) {
+  const char *who = "fpemu_conv2d_fp_f32";
+  Geo g;
+  int rc = make_geo(who, g, N, C, H, W, K, R, S, stride, pad);
+  if (rc != FPEMU_OK) return rc;
+  if (N == 0) return FPEMU_OK;
+  if (!out || !in || !w || !ws) return fail(who, FPEMU_EINVAL, "null buffer");
+  if ((uintptr_t)ws % 16u) return fail(who, FPEMU_EALIGN, "workspace not 16-byte aligned");
+  int64_t wf, per;
+  ws_layout(FPEMU_CONV_FP, g, wf, per);
+  const int64_t chunk = chunk_images(g, per, (int64_t)(ws_bytes / 4) - wf);
+  if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
+  hipStream_t s = (hipStream_t)stream;
+  float *Wm = (float *)ws, *cols = Wm + wf;
+  const int64_t P = g.OH * g.OW, crs = C * R * S;
+  hipLaunchKernelGGL(pack_w_fp, dim3(blocks_for(K * crs)), dim3(NT), 0, s, w, Wm, g);
+  hipLaunchKernelGGL(fill_rows, dim3(blocks_for(N * K * P)), dim3(NT), 0, s, out, bias, K, P, N * K * P,
+                     (int)(C % 64 != 0));
+  CHECK_LAUNCH(who);
+  for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+    const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
+    hipLaunchKernelGGL(cols_fp, dim3(blocks_for(nb * crs * P)), dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb);
+    CHECK_LAUNCH(who);
+    rc = fpemu_gemm_chain_f32(out + n0 * K * P, Wm, cols, K, P, crs, crs, P, P, 0, 0, variant, nb, 0, crs * P,
+                              K * P, stream);
+    if (rc != FPEMU_OK) return rc;
+  }
+  return FPEMU_OK;
+}
+
+int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N, int64_t C, int64_t H,
+                        int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad, int variant,
+                        void *ws, uint64_t ws_bytes, void *stream) {
+  const char *who = "fpemu_conv2d_bp_f32";
+  Geo g;
+  int rc = make_geo(who, g, N, C, H, W, K, R, S, stride, pad);
+  if (rc != FPEMU_OK) return rc;
+  if (N == 0) return FPEMU_OK;
+  if (!gin || !gout || !w || !ws) return fail(who, FPEMU_EINVAL, "null buffer");
+  if ((uintptr_t)ws % 16u) return fail(who, FPEMU_EALIGN, "workspace not 16-byte aligned");
+  int64_t wf, per;
+  ws_layout(FPEMU_CONV_BP, g, wf, per);
+  const int64_t chunk = chunk_images(g, per, (int64_t)(ws_bytes / 4) - wf);
+  if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
+  hipStream_t s = (hipStream_t)stream;
+  float *Wm = (float *)ws, *cols = Wm + wf;
+  const int64_t HW = H * W, krs = K * R * S, P = g.OH * g.OW;
+  hipLaunchKernelGGL(pack_w_bp, dim3(blocks_for(C * krs)), dim3(NT), 0, s, w, Wm, g);
+  hipLaunchKernelGGL(fill_rows, dim3(blocks_for(N * C * HW)), dim3(NT), 0, s, gin, (const float *)nullptr, C, HW,
+                     N * C * HW, 0);
+  CHECK_LAUNCH(who);
+  for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+    const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
+    hipLaunchKernelGGL(cols_bp, dim3(blocks_for(nb * krs * HW)), dim3(NT), 0, s, gout + n0 * K * P, cols, g, nb);
+    CHECK_LAUNCH(who);
+    rc = fpemu_gemm_chain_f32(gin + n0 * C * HW, Wm, cols, C, HW, krs, krs, HW, HW, 0, 0, variant, nb, 0, krs * HW,
+                              C * HW, stream);
+    if (rc != FPEMU_OK) return rc;
+  }
+  return FPEMU_OK;
+}
+
+int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N, int64_t C, int64_t H,
+                        int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad, int variant,
+                        void *ws, uint64_t ws_bytes, void *stream) {
+  const char *who = "fpemu_conv2d_wu_f32";
+  Geo g;
+  int rc = make_geo(who, g, N, C, H, W, K, R, S, stride, pad);
+  if (rc != FPEMU_OK) return rc;
+  if (!gw || !ws || (N > 0 && (!gout || !in))) return fail(who, FPEMU_EINVAL, "null buffer");
+  if ((uintptr_t)ws % 16u) return fail(who, FPEMU_EALIGN, "workspace not 16-byte aligned");
+  int64_t wf, per;
+  ws_layout(FPEMU_CONV_WU, g, wf, per);
+  const int64_t chunk = N == 0 ? 1 : chunk_images(g, per, (int64_t)(ws_bytes / 4) - wf);
+  if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
+  hipStream_t s = (hipStream_t)stream;
+  float *Gm = (float *)ws, *cols = Gm + wf;
+  const int64_t P = g.OH * g.OW, crs = C * R * S;
+  hipLaunchKernelGGL(fill_rows, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, (const float *)nullptr, K, crs,
+                     K * crs, 0);
+  CHECK_LAUNCH(who);
+  for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+    const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
+    hipLaunchKernelGGL(cols_fp, dim3(blocks_for(nb * crs * P)), dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb);
+    CHECK_LAUNCH(who);
+    for (int64_t n = 0; n < nb; n++) {  // one chain across images: launches in image order on one stream
+      rc = fpemu_gemm_chain_f32(Gm, gout + (n0 + n) * K * P, cols + n * crs * P, K, crs, P, P, P, crs, 0, 1,
+                                variant, 1, 0, 0, 0, stream);
+      if (rc != FPEMU_OK) return rc;
+    }
+  }
+  hipLaunchKernelGGL(unpack_gw, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, gw, g);
+  CHECK_LAUNCH(who);
+  return FPEMU_OK;
+}
+
+}  // extern "C"

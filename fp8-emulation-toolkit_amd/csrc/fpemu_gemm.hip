@@ -20,6 +20,7 @@
 //                    VALU at one multiply + one add per MAC = 78.6 TFLOP/s.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/fpemu_hip.h"
 
@@ -127,10 +128,21 @@ __device__ __forceinline__ float epilogue(float c_in, float acc, float alpha, fl
   return c_in + w;
 }
 
-template <bool A_KCONT, bool B_KCONT>
+// Batch: blockIdx.y selects the problem; operands advance by their batch strides (0 = shared).
+struct Batch {
+  int64_t sa, sb, sc;
+};
+
+// CHAIN = false: acc starts at +0 and C = C + (alpha*acc + beta*C)      (simple_gemm, impl.cpp:226-231)
+// CHAIN = true : acc starts at C's current value and C = acc             (the conv kernels: MMEngine loads
+//                C, continues the chain and stores it back, simple_mm_engine.cpp:18-24)
+template <bool A_KCONT, bool B_KCONT, bool CHAIN>
 __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, float *C, int64_t ldc,
                                                        int c_vec, float alpha, float beta,
-                                                       int tiles_m, int tiles_n) {
+                                                       int tiles_m, int tiles_n, Batch bt) {
+  A.p += (int64_t)blockIdx.y * bt.sa;
+  B.p += (int64_t)blockIdx.y * bt.sb;
+  C += (int64_t)blockIdx.y * bt.sc;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
   const int tid = threadIdx.x;
@@ -144,7 +156,13 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 #pragma unroll
   for (int i = 0; i < 8; i++)
 #pragma unroll
-    for (int j = 0; j < 8; j++) acc[i][j] = 0.f;
+    for (int j = 0; j < 8; j++) {
+      acc[i][j] = 0.f;
+      if constexpr (CHAIN) {
+        const int r = m0 + (i >> 2) * 64 + ty * 4 + (i & 3), c = n0 + (j >> 2) * 64 + tx * 4 + (j & 3);
+        if (r < A.R && c < B.R) acc[i][j] = C[(int64_t)r * ldc + c];
+      }
+    }
 
   f32x4 pa[2], pb[2];
   tile_load<A_KCONT>(A, m0, 0, tid, pa);
@@ -196,7 +214,11 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
       for (int jh = 0; jh < 2; jh++) {
         const int c = n0 + jh * 64 + tx * 4;
         float *dst = C + (int64_t)r * ldc + c;
-        if (c_vec && c + 3 < N) {
+        if constexpr (CHAIN) {
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++)
+            if (c + jj < N) dst[jj] = acc[ih * 4 + ii][jh * 4 + jj];
+        } else if (c_vec && c + 3 < N) {
           f32x4 ci = *reinterpret_cast<const f32x4 *>(dst), o;
 #pragma unroll
           for (int jj = 0; jj < 4; jj++) o[jj] = epilogue(ci[jj], acc[ih * 4 + ii][jh * 4 + jj], alpha, beta);
@@ -215,9 +237,13 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 // 128x128 tile as 2x2 MFMA 32x32 tiles.  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5]
 // and B[k = l>>5][j = l&31]; D[reg]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 // ---------------------------------------------------------------------------------------------
-template <bool A_KCONT, bool B_KCONT>
+template <bool A_KCONT, bool B_KCONT, bool CHAIN>
 __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
-                                                       float alpha, float beta, int tiles_m, int tiles_n) {
+                                                       float alpha, float beta, int tiles_m, int tiles_n,
+                                                       Batch bt) {
+  A.p += (int64_t)blockIdx.y * bt.sa;
+  B.p += (int64_t)blockIdx.y * bt.sb;
+  C += (int64_t)blockIdx.y * bt.sc;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -234,7 +260,14 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; r++) {
+        acc[i][j][r] = 0.f;
+        if constexpr (CHAIN) {
+          const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int col = n0 + wn + j * 32 + li;
+          if (row < A.R && col < B.R) acc[i][j][r] = C[(int64_t)row * ldc + col];
+        }
+      }
 
   f32x4 pa[2], pb[2];
   tile_load<A_KCONT>(A, m0, 0, tid, pa);
@@ -283,54 +316,82 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
         const int col = n0 + wn + j * 32 + li;
         if (row < M && col < N) {
           float *dst = C + (int64_t)row * ldc + col;
-          *dst = epilogue(*dst, acc[i][j][r], alpha, beta);
+          if constexpr (CHAIN) *dst = acc[i][j][r];
+          else *dst = epilogue(*dst, acc[i][j][r], alpha, beta);
         }
       }
 }
 
-typedef void (*seqk_fn)(Operand, Operand, float *, int64_t, int, float, float, int, int);
-typedef void (*mfma_fn)(Operand, Operand, float *, int64_t, float, float, int, int);
+typedef void (*seqk_fn)(Operand, Operand, float *, int64_t, int, float, float, int, int, Batch);
+typedef void (*mfma_fn)(Operand, Operand, float *, int64_t, float, float, int, int, Batch);
 
 bool aligned16(const void *p) { return ((uintptr_t)p % 16u) == 0; }
 
-}  // namespace
+template <bool CHAIN> seqk_fn pick_seqk(bool a_kcont, bool b_kcont) {
+  return a_kcont ? (b_kcont ? gemm_seqk_kernel<true, true, CHAIN> : gemm_seqk_kernel<true, false, CHAIN>)
+                 : (b_kcont ? gemm_seqk_kernel<false, true, CHAIN> : gemm_seqk_kernel<false, false, CHAIN>);
+}
+template <bool CHAIN> mfma_fn pick_mfma(bool a_kcont, bool b_kcont) {
+  return a_kcont ? (b_kcont ? gemm_mfma_kernel<true, true, CHAIN> : gemm_mfma_kernel<true, false, CHAIN>)
+                 : (b_kcont ? gemm_mfma_kernel<false, true, CHAIN> : gemm_mfma_kernel<false, false, CHAIN>);
+}
 
-extern "C" int fpemu_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
-                              int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans,
-                              int b_trans, int variant, void *stream) {
-  auto fail = [](int code, const char *msg) { fpemu_set_error_(msg); return code; };
-  if (M <= 0 || N <= 0) return FPEMU_OK;
-  if (C == nullptr || (K > 0 && (A == nullptr || B == nullptr))) return fail(FPEMU_EINVAL, "fpemu_gemm_f32: null matrix");
-  if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || K < 0)
-    return fail(FPEMU_EINVAL, "fpemu_gemm_f32: dimension out of range");
+int launch_gemm(const char *who, float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans, int variant,
+                bool chain, int64_t batch, Batch bt, void *stream) {
+  char msg[160];
+  auto fail = [&](int code, const char *what) {
+    snprintf(msg, sizeof(msg), "%s: %s", who, what);
+    fpemu_set_error_(msg);
+    return code;
+  };
+  if (M <= 0 || N <= 0 || batch <= 0) return FPEMU_OK;
+  if (C == nullptr || (K > 0 && (A == nullptr || B == nullptr))) return fail(FPEMU_EINVAL, "null matrix");
+  if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || K < 0 || batch > 65535)
+    return fail(FPEMU_EINVAL, "dimension out of range");
   if (((uintptr_t)C % 4u) || ((uintptr_t)A % 4u) || ((uintptr_t)B % 4u))
-    return fail(FPEMU_EALIGN, "fpemu_gemm_f32: matrix not aligned to 4 bytes");
+    return fail(FPEMU_EALIGN, "matrix not aligned to 4 bytes");
   // op(A) is M x K: stored [M][K] (k contiguous) or, transposed, [K][M].  op(B) is K x N: stored
   // [K][N] (n contiguous) or, transposed, [N][K] (k contiguous).   (simple_gemm.cpp:52-65)
   Operand a, b;
   a.p = A; a.ld = lda; a.R = (int)M; a.K = (int)K;
   b.p = B; b.ld = ldb; b.R = (int)N; b.K = (int)K;
   const bool a_kcont = !a_trans, b_kcont = b_trans != 0;
-  a.vec = aligned16(A) && (lda % 4 == 0) && ((a_kcont ? K : M) % 4 == 0);
-  b.vec = aligned16(B) && (ldb % 4 == 0) && ((b_kcont ? K : N) % 4 == 0);
-  const int c_vec = aligned16(C) && (ldc % 4 == 0) && (N % 4 == 0);
+  a.vec = aligned16(A) && (lda % 4 == 0) && (bt.sa % 4 == 0) && ((a_kcont ? K : M) % 4 == 0);
+  b.vec = aligned16(B) && (ldb % 4 == 0) && (bt.sb % 4 == 0) && ((b_kcont ? K : N) % 4 == 0);
+  const int c_vec = aligned16(C) && (ldc % 4 == 0) && (bt.sc % 4 == 0) && (N % 4 == 0);
   const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
   const int64_t nwg = (int64_t)tiles_m * tiles_n;
-  if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "fpemu_gemm_f32: too many tiles");
+  if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "too many tiles");
   const float beta = 0.0f;  // simple_gemm.cpp:58
   hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)nwg, (unsigned)batch);
   if (variant == 0) {
-    seqk_fn fn = a_kcont ? (b_kcont ? gemm_seqk_kernel<true, true> : gemm_seqk_kernel<true, false>)
-                         : (b_kcont ? gemm_seqk_kernel<false, true> : gemm_seqk_kernel<false, false>);
-    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(NT), 0, s, a, b, C, ldc, c_vec, alpha, beta, tiles_m,
-                       tiles_n);
+    seqk_fn fn = chain ? pick_seqk<true>(a_kcont, b_kcont) : pick_seqk<false>(a_kcont, b_kcont);
+    hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, c_vec, alpha, beta, tiles_m, tiles_n, bt);
   } else if (variant == 1) {
-    mfma_fn fn = a_kcont ? (b_kcont ? gemm_mfma_kernel<true, true> : gemm_mfma_kernel<true, false>)
-                         : (b_kcont ? gemm_mfma_kernel<false, true> : gemm_mfma_kernel<false, false>);
-    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(NT), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n);
+    mfma_fn fn = chain ? pick_mfma<true>(a_kcont, b_kcont) : pick_mfma<false>(a_kcont, b_kcont);
+    hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);
   } else {
-    return fail(FPEMU_EINVAL, "fpemu_gemm_f32: unknown variant");
+    return fail(FPEMU_EINVAL, "unknown variant");
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FPEMU_OK : fail((int)e, hipGetErrorString(e));
+}
+
+}  // namespace
+
+extern "C" int fpemu_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                              int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans,
+                              int b_trans, int variant, void *stream) {
+  return launch_gemm("fpemu_gemm_f32", C, A, B, M, N, K, lda, ldb, ldc, alpha, a_trans, b_trans, variant, false,
+                     1, Batch{0, 0, 0}, stream);
+}
+
+extern "C" int fpemu_gemm_chain_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                                    int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans,
+                                    int variant, int64_t batch, int64_t stride_a, int64_t stride_b,
+                                    int64_t stride_c, void *stream) {
+  return launch_gemm("fpemu_gemm_chain_f32", C, A, B, M, N, K, lda, ldb, ldc, 1.0f, a_trans, b_trans, variant,
+                     true, batch, Batch{stride_a, stride_b, stride_c}, stream);
 }

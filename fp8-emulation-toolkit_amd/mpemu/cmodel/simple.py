@@ -11,9 +11,11 @@ rounds the product and the sum separately (oracle/build_ref.py builds both; test
 `set_accumulation("fma")` (default, = the reference as built here; runs on the fp32 MFMA, which is
 bit-for-bit that chain) or `set_accumulation("separate")` (explicit per-step rounding, VALU kernel).
 
-Not in this build: conv2d (reference simple_conv2d_*) -- raises.
-Divergence: backward zero-initialises the gradient buffers (the reference accumulates into
-torch.empty_like, simple.py:163-164).
+`conv2d` is the c-model's direct convolution (reference simple_conv2d_dev conv2d_fp / _bp / _wu): square
+stride and padding, no dilation, no groups, as the reference.
+Divergences: backward zero-initialises the gradient buffers (the reference accumulates into
+torch.empty_like, simple.py:163-164); unsupported conv arguments raise ValueError instead of sys.exit;
+the batch is convolved image by image also when C or K < 64 (the reference's packing collapses it).
 """
 import warnings
 
@@ -101,8 +103,27 @@ def mm(input, mat2, out=None):
     return fallback_mm(input, mat2, out=out)
 
 
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
-    raise NotImplementedError("mpemu (MI355X build): the cmodel direct convolution is not implemented")
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    if dilation[0] > 1 or dilation[1] > 1:
+        raise ValueError("simple_conv2d does not support dilated convolutions.")
+    if padding[0] != padding[1]:
+        raise ValueError("simple_conv2d does not support non-uniform padding; pad_h must be equal to pad_w.")
+    if stride[0] != stride[1]:
+        raise ValueError("simple_conv2d applies stride[0] in both dimensions; non-square strides are not supported.")
+    if groups > 1:
+        raise ValueError("simple_conv2d does not support grouped convolutions; set groups to 1.")
+    N, C, H, W = input.size()
+    K, _, R, S = weight.size()
+    h_out = (H + 2 * padding[0] - dilation[0] * (R - 1) - 1) // stride[0] + 1
+    w_out = (W + 2 * padding[1] - dilation[1] * (S - 1) - 1) // stride[1] + 1
+    output = torch.empty([N, K, h_out, w_out], device=input.device)
+    return SimpleConv2dFunction.apply(output, input.contiguous(), weight.contiguous(), bias, stride, padding,
+                                      dilation, groups)
 
 
 def _grads(grad_output, mat1, mat2, alpha, a_trans, b_trans):
@@ -151,3 +172,24 @@ class SimpleMatmul(Function):
         mat1, mat2 = ctx.saved_tensors
         g1, g2 = _grads(grad_output, mat1, mat2, ctx.alpha, ctx.a_trans, ctx.b_trans)
         return grad_output, g1, g2, None, None, None
+
+
+class SimpleConv2dFunction(Function):
+    @staticmethod
+    def forward(ctx, output, inputs, weights, bias, stride, padding, dilation, groups):
+        ctx.save_for_backward(inputs, weights)
+        ctx.stride, ctx.padding = stride, padding
+        _hip.conv2d_fp_(output, inputs, weights, None if bias is None else bias.contiguous(), stride[0], padding[0],
+                        _variant)
+        ctx.mark_dirty(output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        inputs, weights = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_inp = torch.empty_like(inputs)
+        grad_wts = torch.empty_like(weights)
+        _hip.conv2d_bp_(grad_inp, grad_output, weights, ctx.stride[0], ctx.padding[0], _variant)
+        _hip.conv2d_wu_(grad_wts, grad_output, inputs, ctx.stride[0], ctx.padding[0], _variant)
+        return grad_output, grad_inp, grad_wts, None, None, None, None, None

@@ -5,8 +5,10 @@
     emulator.optimizer_step(optimizer)
 
 Out of scope in this build and rejected loudly: sparsity / pruning (`pruning_algo` other than
-"none", reference sparse_utils.py / adasparse.py) and CPU op patching with the cmodel
-(`hw_patch="simple"`).  Tensors must live on a ROCm device.
+"none", reference sparse_utils.py / adasparse.py).  Tensors must live on a ROCm device.
+`hw_patch="simple"` is accepted on the GPU: the c-model GEMM / convolution of mpemu.cmodel.simple run
+there (the reference only allows it with device='cpu', mpt_emu.py:150-151, because its c-model is CPU
+code).
 """
 from .e3m4_emu import E3M4Emulator
 from .e4m3_emu import E4M3Emulator
@@ -86,8 +88,6 @@ class MPTEmulator(object):
 
 
 def _check_device(device, hw_patch):
-    if device == 'cuda' and hw_patch.lower() != 'none':
-        raise RuntimeError("mpt_emulator: HW patching ops is only alowed on 'cpu' device.")
     if device != 'cuda' and not str(device).startswith("cuda"):
         raise RuntimeError("mpt_emulator (MI355X build): only ROCm devices are supported, got {}".format(device))
 

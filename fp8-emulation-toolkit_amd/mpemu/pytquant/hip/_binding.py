@@ -63,6 +63,16 @@ def lib():
         i64 = ctypes.c_int64
         L.fpemu_gemm_f32.restype = i32
         L.fpemu_gemm_f32.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, i32, i32, i32, vp]
+        L.fpemu_gemm_chain_f32.restype = i32
+        L.fpemu_gemm_chain_f32.argtypes = [vp, vp, vp] + [i64] * 6 + [i32, i32, i32] + [i64] * 4 + [vp]
+        L.fpemu_conv2d_workspace_bytes.restype = u64
+        L.fpemu_conv2d_workspace_bytes.argtypes = [i32] + [i64] * 9
+        L.fpemu_conv2d_fp_f32.restype = i32
+        L.fpemu_conv2d_fp_f32.argtypes = [vp, vp, vp, vp] + [i64] * 9 + [i32, vp, u64, vp]
+        for nm in ("fpemu_conv2d_bp_f32", "fpemu_conv2d_wu_f32"):
+            f = getattr(L, nm)
+            f.restype = i32
+            f.argtypes = [vp, vp, vp] + [i64] * 9 + [i32, vp, u64, vp]
         L.fpemu_set_max_blocks.restype = None
         L.fpemu_set_max_blocks.argtypes = [i32]
         L.fpemu_quantize_blocks.restype = i32
@@ -285,6 +295,73 @@ def gemm_(C, A, B, alpha=1.0, a_trans=False, b_trans=False, variant=GEMM_FMA):
                                     C.shape[1], float(alpha), int(bool(a_trans)), int(bool(b_trans)),
                                     int(variant), _stream(C)))
     return C
+
+
+CONV_FP, CONV_BP, CONV_WU = 0, 1, 2
+
+
+def _conv_ws(kind, dims, like):
+    nbytes = lib().fpemu_conv2d_workspace_bytes(kind, *dims)
+    if nbytes == 0:
+        _check(-1 if lib().fpemu_last_error() else 0)
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=like.device), nbytes
+
+
+def _conv_check(ts):
+    for t, what in ts:
+        _require_device(t, what)
+        if t.dtype != torch.float32:
+            raise TypeError("fpemu conv2d: %s must be float32" % what)
+
+
+def conv2d_fp_(output, input, weight, bias, stride, padding, variant=GEMM_FMA):
+    """simple_conv2d_dev.conv2d_fp(output, input, weight, bias, stride, padding, 1, 1) of the reference
+    (cmodel/simple/simple_conv2d.cpp:44-69) on the GPU; output [N,K,OH,OW] is overwritten."""
+    _conv_check([(output, "output"), (input, "input"), (weight, "weight")] + ([(bias, "bias")] if bias is not None else []))
+    N, C, H, W = input.shape
+    K, C1, R, S = weight.shape
+    dims = (N, C, H, W, K, R, S, int(stride), int(padding))
+    OH, OW = (H + 2 * padding - R) // stride + 1, (W + 2 * padding - S) // stride + 1
+    if C1 != C or tuple(output.shape) != (N, K, OH, OW) or (bias is not None and bias.numel() != K):
+        raise ValueError("fpemu conv2d_fp: shapes do not match")
+    with _on_device(input):
+        ws, nbytes = _conv_ws(CONV_FP, dims, input)
+        _check(lib().fpemu_conv2d_fp_f32(output.data_ptr(), input.data_ptr(), weight.data_ptr(),
+                                         None if bias is None else bias.data_ptr(), *dims, int(variant),
+                                         ws.data_ptr(), nbytes, _stream(input)))
+    return output
+
+
+def conv2d_bp_(grad_input, grad_output, weight, stride, padding, variant=GEMM_FMA):
+    """conv2d_bp of the reference (simple_conv2d.cpp:71-95): grad_input [N,C,H,W] is overwritten."""
+    _conv_check([(grad_input, "grad_input"), (grad_output, "grad_output"), (weight, "weight")])
+    N, C, H, W = grad_input.shape
+    K, C1, R, S = weight.shape
+    dims = (N, C, H, W, K, R, S, int(stride), int(padding))
+    OH, OW = (H + 2 * padding - R) // stride + 1, (W + 2 * padding - S) // stride + 1
+    if C1 != C or tuple(grad_output.shape) != (N, K, OH, OW):
+        raise ValueError("fpemu conv2d_bp: shapes do not match")
+    with _on_device(grad_input):
+        ws, nbytes = _conv_ws(CONV_BP, dims, grad_input)
+        _check(lib().fpemu_conv2d_bp_f32(grad_input.data_ptr(), grad_output.data_ptr(), weight.data_ptr(), *dims,
+                                         int(variant), ws.data_ptr(), nbytes, _stream(grad_input)))
+    return grad_input
+
+
+def conv2d_wu_(grad_weight, grad_output, input, stride, padding, variant=GEMM_FMA):
+    """conv2d_wu of the reference (simple_conv2d.cpp:97-121): grad_weight [K,C,R,S] is overwritten."""
+    _conv_check([(grad_weight, "grad_weight"), (grad_output, "grad_output"), (input, "input")])
+    N, C, H, W = input.shape
+    K, C1, R, S = grad_weight.shape
+    dims = (N, C, H, W, K, R, S, int(stride), int(padding))
+    OH, OW = (H + 2 * padding - R) // stride + 1, (W + 2 * padding - S) // stride + 1
+    if C1 != C or tuple(grad_output.shape) != (N, K, OH, OW):
+        raise ValueError("fpemu conv2d_wu: shapes do not match")
+    with _on_device(input):
+        ws, nbytes = _conv_ws(CONV_WU, dims, input)
+        _check(lib().fpemu_conv2d_wu_f32(grad_weight.data_ptr(), grad_output.data_ptr(), input.data_ptr(), *dims,
+                                         int(variant), ws.data_ptr(), nbytes, _stream(input)))
+    return grad_weight
 
 
 def forward(input, mode, size, inplace, scale, block_norm=False, block_size=1):

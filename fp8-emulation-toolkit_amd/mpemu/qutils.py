@@ -336,7 +336,10 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
 # The hooks only decide WHICH tensors are cast with WHICH config; every cast goes through
 # quantize_tensor above, i.e. the HIP kernels.  Out of scope here (not on the cast path): the
 # stats collectors, tensor dumps and tensorboard plumbing of the reference (flags are accepted
-# and ignored), and the CPU-only op monkey-patching (`patch_ops`, cmodel).
+# and ignored).  Op patching (`patch_ops`, patch_impl "SIMPLE"): for the duration of a hooked module's
+# forward, torch.addmm / matmul / mm (functions and Tensor methods) and torch.nn.functional.conv2d are
+# replaced by the c-model ops of mpemu.cmodel.simple, as the reference does for CPU modules
+# (qutils.py:480-509, 588-600); here the c-model runs on the GPU, so it applies to GPU modules.
 # ---------------------------------------------------------------------------------------------
 def get_or_update_model_quant_config_dict(model, filter_module_types, mod_qconfig, prefix="",
                                           model_qconfig_dict=None, override=False, exempt_modules=[]):
@@ -377,9 +380,8 @@ def _active(qtconfig):
 def quantize_module_weights_and_inputs(self, input):
     """forward-pre hook: weights in place, then every positional input out of place."""
     qc = self.qconfig
-    if qc.patch_ops and qc.patch_impl not in ("None", "NONE") and any(True for _ in self.parameters()):
-        if not next(self.parameters()).is_cuda:
-            raise NotImplementedError("mpemu (MI355X build): op patching with the CPU cmodel is not available")
+    if qc.patch_ops and qc.patch_impl == "SIMPLE" and any(True for _ in self.parameters()):
+        _patch_ops(self)
     keeps_master = qc.wt_qconfig is not None and (qc.wt_qconfig.dtype in ["bfloat16"] or qc.device == 'cpu')
     if keeps_master:
         qc.weight_master = copy.deepcopy(self.weight.data)
@@ -405,9 +407,41 @@ def quantize_module_gradient(self, grad_input, grad_output):
     return grad_input
 
 
+_PATCHED = (("addmm", "addmm"), ("matmul", "matmul"), ("mm", "mm"))
+
+
+def _patch_ops(module):
+    """Swap in the c-model ops (reference qutils.py:489-509); undone by the module's forward hook."""
+    from .cmodel import simple as hw_impl
+    if getattr(module, "_mpemu_saved_ops", None) is not None:
+        return
+    saved = {}
+    for tname, sname in _PATCHED:
+        saved["torch." + tname] = getattr(torch, tname)
+        saved["Tensor." + tname] = getattr(torch.Tensor, tname)
+        setattr(torch, tname, getattr(hw_impl, sname))
+        setattr(torch.Tensor, tname, getattr(hw_impl, sname))
+    saved["F.conv2d"] = torch.nn.functional.conv2d
+    torch.nn.functional.conv2d = hw_impl.conv2d
+    module._mpemu_saved_ops = saved
+
+
+def _unpatch_ops(module):
+    saved = getattr(module, "_mpemu_saved_ops", None)
+    if saved is None:
+        return
+    for tname, _ in _PATCHED:
+        setattr(torch, tname, saved["torch." + tname])
+        setattr(torch.Tensor, tname, saved["Tensor." + tname])
+    torch.nn.functional.conv2d = saved["F.conv2d"]
+    module._mpemu_saved_ops = None
+
+
 def quantize_module_output(self, input, output):
-    """forward hook: registers the output-gradient hook, then casts the output in place."""
+    """forward hook: restores patched ops, registers the output-gradient hook, then casts the output in
+    place."""
     qc = self.qconfig
+    _unpatch_ops(self)
     qc.register_output_grad_hook(output)
     if _active(qc.oact_qconfig):
         output = quantize_tensor(output, qc.oact_qconfig, self.qparams.oact_qparams, inplace=True)

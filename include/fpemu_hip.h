@@ -168,6 +168,40 @@ int fpemu_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t 
                    int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans,
                    int variant, void *stream);
 
+/* Chain-mode (and batched) form of the cmodel GEMM, the building block of the cmodel convolution: the
+ * accumulators START at C's current values and C = acc (what MMEngine_avx2_ps does inside the
+ * reference's conv kernels: load C, continue the k-ascending chain, store; simple_mm_engine.cpp:18-24),
+ * instead of simple_gemm's C += alpha*acc.  `batch` independent problems; operand b is at
+ * X + b*stride_x elements (stride 0 = shared).  variant as fpemu_gemm_f32. */
+int fpemu_gemm_chain_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                         int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans, int variant,
+                         int64_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, void *stream);
+
+/* cmodel direct convolution: replaces simple_conv2d_dev.conv2d_fp / conv2d_bp / conv2d_wu
+ * (mpemu/cmodel/simple/simple_conv2d.cpp:44-121 -> simple_conv2d_impl.cpp:677-977).  NCHW activations,
+ * KCRS weights, fp32, square stride and padding, no dilation, no groups (simple.py:98-103).  Every
+ * result element is the reference's serial accumulation chain (csrc/fpemu_conv.hip states the three
+ * orders); variant selects fmaf chain (1, = the reference as built on FMA hosts) or separate roundings
+ * (0).  C and K must each be <= 64 or a multiple of 64.  bias may be NULL (zeros, simple.py:193-196).
+ *   fp: out [N,K,OH,OW]  <- in [N,C,H,W], w [K,C,R,S], bias [K]
+ *   bp: gin [N,C,H,W]    <- gout [N,K,OH,OW], w         (gin is overwritten, not accumulated)
+ *   wu: gw  [K,C,R,S]    <- gout, in                     (gw is overwritten)
+ * ws: caller-owned device workspace of at least fpemu_conv2d_workspace_bytes(kind, ...) bytes, 16-byte
+ * aligned (packed weights + the gathered GEMM operand of a chunk of images); a smaller one still works
+ * while it holds one image.  No allocation, no host sync. */
+enum { FPEMU_CONV_FP = 0, FPEMU_CONV_BP = 1, FPEMU_CONV_WU = 2 };
+uint64_t fpemu_conv2d_workspace_bytes(int kind, int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
+                                      int64_t R, int64_t S, int64_t stride, int64_t pad);
+int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float *bias, int64_t N, int64_t C,
+                        int64_t H, int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                        int variant, void *ws, uint64_t ws_bytes, void *stream);
+int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N, int64_t C, int64_t H,
+                        int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad, int variant,
+                        void *ws, uint64_t ws_bytes, void *stream);
+int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N, int64_t C, int64_t H,
+                        int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad, int variant,
+                        void *ws, uint64_t ws_bytes, void *stream);
+
 /* Launch-geometry override for benchmarking sweeps: blocks per launch cap (0 = default).
  * Affects performance only, never results. */
 void fpemu_set_max_blocks(int max_blocks);

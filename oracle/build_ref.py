@@ -120,8 +120,9 @@ def main():
     for which in ("simple_gemm_dev", "simple_conv2d_dev"):
         m = load_cmodel(which, verbose=v)
         print("oracle/_ref/%s: built %s" % (which, m.__file__))
-    m = load_cmodel("simple_gemm_dev", verbose=v, nofma=True)
-    print("oracle/_ref/simple_gemm_dev_nofma: built %s" % m.__file__)
+    for which in ("simple_gemm_dev", "simple_conv2d_dev"):
+        m = load_cmodel(which, verbose=v, nofma=True)
+        print("oracle/_ref/%s_nofma: built %s" % (which, m.__file__))
     return 0
 
 

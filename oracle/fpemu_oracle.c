@@ -568,3 +568,112 @@ void orc_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t N
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * cmodel direct convolution: simple_conv2d_impl_{fp,bp,wu} (mpemu/cmodel/simple/simple_conv2d_impl.cpp
+ * :677-977) with gemm_kernel_conv_{fp,bp,wu} (:372-675) on MMEngine_avx2_ps / MMEngine_strideB_avx2_ps
+ * (simple_mm_engine.cpp:13-44).  Square stride and padding, no dilation, no groups (simple.py:98-103).
+ * What is restated is the accumulation chain of every result element as ONE thread executes the
+ * reference (its OpenMP loops over ifm1 / ofm1 / oj race on shared results, so only the serial order is
+ * defined).  The engine loads the running value, continues the chain over its k loop, stores it back:
+ *   fp: out[n][k][oj][oi]  = bias[k]; for cb, kj, ki, c2 (c = cb*CB + c2): += w[k][c][kj][ki] * x_pad
+ *   bp: gin[n][c][y][x]    = +0;      for ob, oj ascending (kj = y+pad - oj*s), ki ascending
+ *                                     (oi = (x+pad - ki)/s), o2: += w[k][c][kj][ki] * gout[n][k][oj][oi]
+ *   wu: gw[k][c][kj][ki]   = +0;      for n, oj, oi: += gout[n][k][oj][oi] * x_pad[n][c][oj*s+kj][oi*s+ki]
+ * CB = 64-channel blocks (the whole C when C < 64).  Zero-padded taps ARE multiplied in fp and wu
+ * (0 * w), as the reference does on its padded buffers; channel padding to 64 only adds +0 terms, which
+ * matter for one case: a -0 bias becomes +0 when C % 64 != 0.  `fused` as in orc_gemm_f32.
+ * The reference is only defined for C, K each < 64 or a multiple of 64 (its packing routines drop or
+ * over-read channels otherwise, :143-160, :282-307); returns -1 for other shapes.
+ * ---------------------------------------------------------------------------------------- */
+static inline float mac(float acc, float a, float b, int fused) {
+  if (fused) return fmaf(a, b, acc);
+  volatile float p = a * b;
+  return acc + p;
+}
+
+static int conv_shape_ok(int64_t C, int64_t K, int64_t stride, int64_t pad, int64_t H, int64_t W, int64_t R,
+                         int64_t S) {
+  if (stride < 1 || pad < 0 || H + 2 * pad < R || W + 2 * pad < S) return 0;
+  if (C < 1 || K < 1 || (C > 64 && C % 64) || (K > 64 && K % 64)) return 0;
+  return 1;
+}
+
+int orc_conv2d_fp(float *out, const float *in, const float *w, const float *bias, int64_t N, int64_t C,
+                  int64_t H, int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                  int fused) {
+  if (!conv_shape_ok(C, K, stride, pad, H, W, R, S)) return -1;
+  const int64_t OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+  const int64_t CB = C < 64 ? C : 64;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int64_t n = 0; n < N; n++)
+    for (int64_t k = 0; k < K; k++)
+      for (int64_t oj = 0; oj < OH; oj++)
+        for (int64_t oi = 0; oi < OW; oi++) {
+          float acc = bias ? bias[k] : 0.0f;
+          if (C % 64) acc = acc + 0.0f; /* the +0 terms of the padded channels */
+          for (int64_t cb = 0; cb < C / CB; cb++)
+            for (int64_t kj = 0; kj < R; kj++)
+              for (int64_t ki = 0; ki < S; ki++)
+                for (int64_t c2 = 0; c2 < CB; c2++) {
+                  const int64_t c = cb * CB + c2, y = oj * stride + kj - pad, x = oi * stride + ki - pad;
+                  const float xv = (y >= 0 && y < H && x >= 0 && x < W) ? in[((n * C + c) * H + y) * W + x] : 0.0f;
+                  acc = mac(acc, w[((k * C + c) * R + kj) * S + ki], xv, fused);
+                }
+          out[((n * K + k) * OH + oj) * OW + oi] = acc;
+        }
+  return 0;
+}
+
+int orc_conv2d_bp(float *gin, const float *gout, const float *w, int64_t N, int64_t C, int64_t H, int64_t W,
+                  int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad, int fused) {
+  if (!conv_shape_ok(C, K, stride, pad, H, W, R, S)) return -1;
+  const int64_t OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+  const int64_t KB = K < 64 ? K : 64;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int64_t n = 0; n < N; n++)
+    for (int64_t c = 0; c < C; c++)
+      for (int64_t ih = 0; ih < H; ih++)
+        for (int64_t iw = 0; iw < W; iw++) {
+          const int64_t y = ih + pad, x = iw + pad;
+          float acc = 0.0f;
+          for (int64_t ob = 0; ob < K / KB; ob++)
+            for (int64_t oj = 0; oj < OH; oj++) {
+              const int64_t kj = y - oj * stride;
+              if (kj < 0 || kj >= R) continue;
+              for (int64_t ki = 0; ki < S; ki++) {
+                const int64_t d = x - ki;
+                if (d < 0 || d % stride || d / stride >= OW) continue;
+                const int64_t oi = d / stride;
+                for (int64_t o2 = 0; o2 < KB; o2++) {
+                  const int64_t k = ob * KB + o2;
+                  acc = mac(acc, w[((k * C + c) * R + kj) * S + ki], gout[((n * K + k) * OH + oj) * OW + oi], fused);
+                }
+              }
+            }
+          gin[((n * C + c) * H + ih) * W + iw] = acc;
+        }
+  return 0;
+}
+
+int orc_conv2d_wu(float *gw, const float *gout, const float *in, int64_t N, int64_t C, int64_t H, int64_t W,
+                  int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad, int fused) {
+  if (!conv_shape_ok(C, K, stride, pad, H, W, R, S)) return -1;
+  const int64_t OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int64_t k = 0; k < K; k++)
+    for (int64_t c = 0; c < C; c++)
+      for (int64_t kj = 0; kj < R; kj++)
+        for (int64_t ki = 0; ki < S; ki++) {
+          float acc = 0.0f;
+          for (int64_t n = 0; n < N; n++)
+            for (int64_t oj = 0; oj < OH; oj++)
+              for (int64_t oi = 0; oi < OW; oi++) {
+                const int64_t y = oj * stride + kj - pad, x = oi * stride + ki - pad;
+                const float xv = (y >= 0 && y < H && x >= 0 && x < W) ? in[((n * C + c) * H + y) * W + x] : 0.0f;
+                acc = mac(acc, gout[((n * K + k) * OH + oj) * OW + oi], xv, fused);
+              }
+          gw[((k * C + c) * R + kj) * S + ki] = acc;
+        }
+  return 0;
+}

@@ -112,6 +112,18 @@ void orc_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t N
                   int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans,
                   int fused);
 
+/* cmodel direct convolution, forward / backward-data / weight-update (reference
+ * simple_conv2d_impl.cpp:677-977): NCHW / KCRS fp32, square stride and padding.  Chains documented in
+ * the .c.  Return 0, or -1 for shapes the reference itself mishandles (C or K > 64 and not a multiple
+ * of 64). */
+int orc_conv2d_fp(float *out, const float *in, const float *w, const float *bias, int64_t N, int64_t C,
+                  int64_t H, int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                  int fused);
+int orc_conv2d_bp(float *gin, const float *gout, const float *w, int64_t N, int64_t C, int64_t H, int64_t W,
+                  int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad, int fused);
+int orc_conv2d_wu(float *gw, const float *gout, const float *in, int64_t N, int64_t C, int64_t H, int64_t W,
+                  int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad, int fused);
+
 /* Number of OpenMP threads the library will use (1 when built without OpenMP). */
 int orc_num_threads(void);
 

@@ -68,6 +68,10 @@ def lib():
     i64 = ctypes.c_int64
     L.orc_gemm_f32.restype = None
     L.orc_gemm_f32.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, i32, i32, i32]
+    for nm, nptr in (("orc_conv2d_fp", 4), ("orc_conv2d_bp", 3), ("orc_conv2d_wu", 3)):
+        f = getattr(L, nm)
+        f.restype = i32
+        f.argtypes = [vp] * nptr + [i64] * 9 + [i32]
     L.orc_num_threads.restype = i32
     L.orc_num_threads.argtypes = []
     _lib = L
@@ -159,6 +163,50 @@ def gemm(a, b, alpha=1.0, a_trans=False, b_trans=False, out=None, fused=False):
     lib().orc_gemm_f32(_ptr(c), _ptr(a), _ptr(b), M, N, K, a.shape[1], b.shape[1], c.shape[1],
                        np.float32(alpha), int(a_trans), int(b_trans), int(fused))
     return c
+
+
+def _conv_out_hw(H, W, R, S, stride, pad):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+
+
+def conv2d_fp(x, w, bias=None, stride=1, pad=0, fused=True):
+    """Oracle of simple_conv2d_dev.conv2d_fp: x [N,C,H,W], w [K,C,R,S] -> [N,K,OH,OW]."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    N, C, H, W = x.shape
+    K, _, R, S = w.shape
+    OH, OW = _conv_out_hw(H, W, R, S, stride, pad)
+    b = np.zeros(K, dtype=np.float32) if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    out = np.empty((N, K, OH, OW), dtype=np.float32)
+    if lib().orc_conv2d_fp(_ptr(out), _ptr(x), _ptr(w), _ptr(b), N, C, H, W, K, R, S, stride, pad, int(fused)):
+        raise ValueError("oracle: conv2d shape the reference does not define")
+    return out
+
+
+def conv2d_bp(gout, w, in_hw, stride=1, pad=0, fused=True):
+    """Oracle of conv2d_bp: gout [N,K,OH,OW], w [K,C,R,S] -> grad input [N,C,H,W]."""
+    gout = np.ascontiguousarray(gout, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    N, K = gout.shape[:2]
+    _, C, R, S = w.shape
+    H, W = in_hw
+    gin = np.empty((N, C, H, W), dtype=np.float32)
+    if lib().orc_conv2d_bp(_ptr(gin), _ptr(gout), _ptr(w), N, C, H, W, K, R, S, stride, pad, int(fused)):
+        raise ValueError("oracle: conv2d shape the reference does not define")
+    return gin
+
+
+def conv2d_wu(gout, x, rs, stride=1, pad=0, fused=True):
+    """Oracle of conv2d_wu: gout [N,K,OH,OW], x [N,C,H,W] -> grad weight [K,C,R,S]."""
+    gout = np.ascontiguousarray(gout, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    N, C, H, W = x.shape
+    K = gout.shape[1]
+    R, S = rs
+    gw = np.empty((K, C, R, S), dtype=np.float32)
+    if lib().orc_conv2d_wu(_ptr(gw), _ptr(gout), _ptr(x), N, C, H, W, K, R, S, stride, pad, int(fused)):
+        raise ValueError("oracle: conv2d shape the reference does not define")
+    return gw
 
 
 def num_threads():

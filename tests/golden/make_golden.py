@@ -18,6 +18,7 @@ Fixtures (all loadable with numpy.load(allow_pickle=False) / json):
   qtensor.npz     reference qutils.quantize_tensor (per-tensor / per-channel / fine-grained / mean)
   models.npz      reference mpt_emu.quantize_model / scale_shift on tiny seeded models
   gemm.npz        reference cmodel simple_gemm_dev.gemm, FMA build and -mno-fma build
+  conv.npz        reference cmodel simple_conv2d_dev conv2d_fp / _bp / _wu, FMA build and -mno-fma build
   ext2.npz        E4M3_IEEE_RNE (AVX-512 routine = canonical), FP4_NEAREST, block_norm=True outputs,
                   E4M3_IEEE_STOCHASTIC round-up counts
 """
@@ -244,6 +245,46 @@ def gen_gemm():
     np.savez_compressed(os.path.join(HERE, "gemm.npz"), **out)
 
 
+CONV_CASES = [  # N, C, H, W, K, R, S, stride, pad
+    (1, 3, 9, 9, 8, 3, 3, 1, 1), (1, 16, 8, 8, 32, 3, 3, 2, 1), (2, 64, 7, 7, 64, 1, 1, 1, 0),
+    (2, 128, 6, 6, 64, 3, 3, 1, 1), (1, 64, 6, 6, 128, 3, 3, 2, 1), (1, 3, 15, 15, 16, 7, 7, 2, 3),
+    (1, 5, 9, 7, 7, 3, 3, 1, 0), (1, 8, 10, 10, 8, 2, 2, 2, 0), (1, 4, 11, 11, 4, 5, 5, 3, 2),
+    (3, 64, 5, 5, 64, 3, 3, 1, 1),
+]
+
+
+def gen_conv():
+    """The reference is run with ONE thread: its OpenMP loops over channel blocks / rows update shared
+    results without synchronisation.  Cases keep to shapes it handles (C, K < 64 with N = 1 -- its packing
+    collapses the batch otherwise -- or multiples of 64)."""
+    builds = {"fma": build_ref.load_cmodel("simple_conv2d_dev"),
+              "nofma": build_ref.load_cmodel("simple_conv2d_dev", nofma=True)}
+    rng = np.random.default_rng(99)
+    out = {"cases": np.array(CONV_CASES, dtype=np.int64)}
+    for ci, (N, C, H, W, K, R, S, st, pd) in enumerate(CONV_CASES):
+        OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        w = (rng.standard_normal((K, C, R, S)) * 0.2).astype(np.float32)
+        b = rng.standard_normal(K).astype(np.float32)
+        go = rng.standard_normal((N, K, OH, OW)).astype(np.float32)
+        if ci == 0:
+            b[1] = -0.0
+            x[0, :, 2, 2] = 0.0
+        for nm, a in (("x", x), ("w", w), ("b", b), ("go", go)):
+            out["%d/%s" % (ci, nm)] = a.view(np.uint32)
+        for bname, m in builds.items():
+            y = torch.empty(N, K, OH, OW)
+            m.conv2d_fp(y, torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), st, pd, 1, 1)
+            gi = torch.zeros(N, C, H, W)
+            m.conv2d_bp(gi, torch.from_numpy(go), torch.from_numpy(w), st, pd, 1, 1)
+            gw = torch.zeros(K, C, R, S)
+            m.conv2d_wu(gw, torch.from_numpy(go), torch.from_numpy(x), st, pd, 1, 1)
+            out["%d/%s/fp" % (ci, bname)] = y.numpy().view(np.uint32)
+            out["%d/%s/bp" % (ci, bname)] = gi.numpy().view(np.uint32)
+            out["%d/%s/wu" % (ci, bname)] = gw.numpy().view(np.uint32)
+    np.savez_compressed(os.path.join(HERE, "conv.npz"), **out)
+
+
 def ref_blocknorm(mod, x, mode, bs):
     t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32).copy())
     return mod.forward(t, mode, t.numel(), False, 1.0, True, int(bs))[0].numpy().view(np.uint32).copy()
@@ -380,7 +421,7 @@ def gen_models():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor", "models", "gemm", "ext2"]
+    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor", "models", "gemm", "ext2", "conv"]
     for w in which:
         globals()["gen_" + w]()
         print("golden:", w, "done")

@@ -1,0 +1,168 @@
+"""cmodel direct convolution on the GPU vs the reference's simple_conv2d_dev (both builds, run
+single-threaded; tests/golden/conv.npz) and vs the oracle's serial accumulation chains.  Bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from _util import assert_bits_equal, npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+VARIANTS = [("fma", 1, True), ("nofma", 0, False)]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mpemu.pytquant.hip import _binding as b
+
+    b.lib()
+    return b
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _run_all(hip, x, w, b, go, st, pd, variant):
+    N, C, H, W = x.shape
+    K, _, R, S = w.shape
+    y = torch.empty(go.shape, device=DEV)
+    hip.conv2d_fp_(y, _t(x), _t(w), None if b is None else _t(b), st, pd, variant)
+    gi = torch.full(x.shape, 7.0, device=DEV)    # overwritten, not accumulated
+    hip.conv2d_bp_(gi, _t(go), _t(w), st, pd, variant)
+    gw = torch.full(w.shape, 7.0, device=DEV)
+    hip.conv2d_wu_(gw, _t(go), _t(x), st, pd, variant)
+    return y.cpu().numpy(), gi.cpu().numpy(), gw.cpu().numpy()
+
+
+@pytest.mark.parametrize("bname,variant,fused", VARIANTS)
+def test_conv_vs_reference_fixture(hip, bname, variant, fused):
+    g = npz("conv.npz")
+    for ci, (N, C, H, W, K, R, S, st, pd) in enumerate(g["cases"].tolist()):
+        OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
+        x = g["%d/x" % ci].view(np.float32).reshape(N, C, H, W)
+        w = g["%d/w" % ci].view(np.float32).reshape(K, C, R, S)
+        b = g["%d/b" % ci].view(np.float32)
+        go = g["%d/go" % ci].view(np.float32).reshape(N, K, OH, OW)
+        y, gi, gw = _run_all(hip, x, w, b, go, st, pd, variant)
+        tag = "%s case %d" % (bname, ci)
+        assert_bits_equal(y, g["%d/%s/fp" % (ci, bname)], tag + " fp")
+        assert_bits_equal(gi, g["%d/%s/bp" % (ci, bname)], tag + " bp")
+        assert_bits_equal(gw, g["%d/%s/wu" % (ci, bname)], tag + " wu")
+
+
+@pytest.mark.parametrize("bname,variant,fused", VARIANTS)
+@pytest.mark.parametrize("case", [(2, 3, 32, 32, 64, 7, 7, 2, 3), (4, 64, 14, 14, 64, 3, 3, 1, 1),
+                                  (3, 16, 9, 11, 24, 3, 3, 1, 1), (2, 128, 8, 8, 128, 1, 1, 2, 0),
+                                  (1, 64, 28, 28, 192, 3, 3, 2, 1), (5, 1, 5, 5, 1, 5, 5, 1, 0)])
+def test_conv_vs_oracle(hip, bname, variant, fused, case):
+    """Batches with C or K < 64 included: every image is convolved (the reference collapses them)."""
+    N, C, H, W, K, R, S, st, pd = case
+    rng = np.random.default_rng(sum(case))
+    OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((K, C, R, S)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    b[0] = -0.0
+    go = rng.standard_normal((N, K, OH, OW)).astype(np.float32)
+    y, gi, gw = _run_all(hip, x, w, b, go, st, pd, variant)
+    assert_bits_equal(y, orc.conv2d_fp(x, w, b, st, pd, fused), "%s %s fp" % (bname, case))
+    assert_bits_equal(gi, orc.conv2d_bp(go, w, (H, W), st, pd, fused), "%s %s bp" % (bname, case))
+    assert_bits_equal(gw, orc.conv2d_wu(go, x, (R, S), st, pd, fused), "%s %s wu" % (bname, case))
+    y0, _, _ = _run_all(hip, x, w, None, go, st, pd, variant)
+    assert_bits_equal(y0, orc.conv2d_fp(x, w, None, st, pd, fused), "no bias")
+
+
+def test_conv_small_workspace_chunks(hip):
+    """A workspace that holds one image only: the batch is processed in chunks, same bits."""
+    N, C, H, W, K, R, S, st, pd = 5, 8, 12, 12, 16, 3, 3, 1, 1
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = rng.standard_normal((K, C, R, S)).astype(np.float32)
+    L = hip.lib()
+    dims = (N, C, H, W, K, R, S, st, pd)
+    full = L.fpemu_conv2d_workspace_bytes(0, *dims)
+    one = L.fpemu_conv2d_workspace_bytes(0, 1, *dims[1:])
+    assert one < full
+    ws = torch.empty(one // 4, device=DEV)
+    tx, tw = _t(x), _t(w)
+    y = torch.empty(N, K, H, W, device=DEV)
+    assert L.fpemu_conv2d_fp_f32(y.data_ptr(), tx.data_ptr(), tw.data_ptr(), None, *dims, 1, ws.data_ptr(), one,
+                                 None) == 0
+    torch.cuda.synchronize()
+    assert_bits_equal(y.cpu().numpy(), orc.conv2d_fp(x, w, None, st, pd, True), "chunked")
+    assert L.fpemu_conv2d_fp_f32(y.data_ptr(), tx.data_ptr(), tw.data_ptr(), None, *dims, 1, ws.data_ptr(), 64,
+                                 None) == -1
+    assert L.fpemu_conv2d_fp_f32(y.data_ptr(), tx.data_ptr(), tw.data_ptr(), None, 1, 96, 4, 4, 8, 1, 1, 1, 0, 1,
+                                 ws.data_ptr(), one, None) == -1   # C = 96: undefined in the reference
+
+
+def test_simple_conv2d_module_api(hip):
+    """mpemu.cmodel.simple.conv2d with autograd, the call torch.nn.functional.conv2d is patched to."""
+    from mpemu.cmodel import simple
+
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2, 8, 10, 10)).astype(np.float32)
+    w = rng.standard_normal((16, 8, 3, 3)).astype(np.float32)
+    b = rng.standard_normal(16).astype(np.float32)
+    tx, tw, tb = _t(x).requires_grad_(True), _t(w).requires_grad_(True), _t(b)
+    y = simple.conv2d(tx, tw, tb, stride=(2, 2), padding=(1, 1), dilation=(1, 1), groups=1)
+    assert_bits_equal(y.detach().cpu().numpy(), orc.conv2d_fp(x, w, b, 2, 1, True), "conv2d")
+    go = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(_t(go))
+    assert_bits_equal(tx.grad.cpu().numpy(), orc.conv2d_bp(go, w, (10, 10), 2, 1, True), "grad input")
+    assert_bits_equal(tw.grad.cpu().numpy(), orc.conv2d_wu(go, x, (3, 3), 2, 1, True), "grad weight")
+    ref = torch.nn.functional.conv2d(_t(x), _t(w), tb, stride=2, padding=1)
+    assert torch.allclose(y.detach(), ref, rtol=1e-4, atol=1e-4)
+    for bad in (dict(dilation=(2, 2)), dict(padding=(1, 0)), dict(groups=2), dict(stride=(1, 2))):
+        with pytest.raises(ValueError):
+            simple.conv2d(tx, tw, tb, **bad)
+
+
+def test_hw_patch_simple_routes_conv_and_matmul_through_cmodel(hip):
+    """mpt_emu.quantize_model(..., hw_patch="simple"): inside a hooked module's forward F.conv2d and
+    torch.matmul are the c-model ops (reference qutils.py:489-509), restored afterwards."""
+    import torch.nn.functional as F
+
+    from mpemu import mpt_emu
+    from mpemu.cmodel import simple
+    from mpemu.module_wrappers import Matmul
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(64, 64, 3, padding=1)
+            self.small = torch.nn.Conv2d(64, 8, 1)     # < 64 channels: left unpatched (e4m3_emu.py:99-104)
+            self.mm = Matmul()
+
+        def forward(self, x):
+            y = self.conv(x)
+            z = self.small(y)
+            return self.mm(z.flatten(2), z.flatten(2).transpose(1, 2).contiguous())
+
+    torch.manual_seed(3)
+    net = Net().to(DEV).eval()
+    seen = []
+    real_conv, real_matmul = simple.conv2d, simple.matmul
+
+    def spy_conv(input, weight, bias=None, *a, **k):
+        out = real_conv(input, weight, bias, *a, **k)
+        seen.append(("conv", input.detach().clone(), weight.detach().clone(), bias.detach().clone(), out.detach().clone()))
+        return out
+
+    simple.conv2d = spy_conv
+    try:
+        orig_conv, orig_matmul = F.conv2d, torch.matmul
+        model, emu = mpt_emu.quantize_model(net, dtype="e4m3", hw_patch="simple", device="cuda")
+        assert "small" in emu.emulator.list_unpatched and "conv" not in emu.emulator.list_unpatched
+        x = torch.randn(2, 64, 6, 6, device=DEV)
+        with torch.no_grad():
+            out = model(x)
+        assert F.conv2d is orig_conv and torch.matmul is orig_matmul and torch.Tensor.matmul is not simple.matmul
+    finally:
+        simple.conv2d = real_conv
+    assert len(seen) == 1 and torch.isfinite(out).all()
+    _, xi, wi, bi, yo = seen[0]
+    want = orc.conv2d_fp(xi.cpu().numpy(), wi.cpu().numpy(), bi.cpu().numpy(), 1, 1, True)
+    assert_bits_equal(yo.cpu().numpy(), want, "patched conv = c-model chain on the quantised operands")

@@ -121,5 +121,3 @@ def test_simple_module_api(hip):
         simple.set_accumulation("fma")
     with pytest.warns(UserWarning):
         simple.mm(_t(a).double(), _t(b).double())
-    with pytest.raises(NotImplementedError):
-        simple.conv2d(None, None)

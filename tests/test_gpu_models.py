@@ -97,7 +97,7 @@ def test_quantize_model_fuse_bn_and_errors():
     with pytest.raises(RuntimeError):
         mpt_emu.quantize_model(_mlp(g), dtype="e4m3", device="cpu")
     with pytest.raises(RuntimeError):
-        mpt_emu.quantize_model(_mlp(g).to(DEV), dtype="e4m3", hw_patch="simple", device="cuda")
+        mpt_emu.quantize_model(_mlp(g).to(DEV), dtype="e4m3", hw_patch="bogus", device="cuda")
 
 
 def _is_fixed_point(t, mode, scale=1.0):

@@ -307,3 +307,21 @@ def test_ext2_e4m3_ieee_stochastic_statistics():
         assert abs(int(n_hi) - N * p) < 5 * sigma, (hex(xb), int(n_hi), N * p)
     sub = g["sr/sub_in"].view(np.float32)
     assert_bits_equal(orc.cast(sub, "E4M3_IEEE_STOCHASTIC", seed=3), g["sr/sub_out"], "sub-range RNE under SR")
+
+
+@pytest.mark.parametrize("build,fused", [("fma", True), ("nofma", False)])
+def test_conv_oracle_matches_reference_builds(build, fused):
+    """orc_conv2d_{fp,bp,wu} vs the reference's simple_conv2d_dev run single-threaded, both builds."""
+    g = npz("conv.npz")
+    for ci, (N, C, H, W, K, R, S, st, pd) in enumerate(g["cases"].tolist()):
+        OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
+        x = g["%d/x" % ci].view(np.float32).reshape(N, C, H, W)
+        w = g["%d/w" % ci].view(np.float32).reshape(K, C, R, S)
+        b = g["%d/b" % ci].view(np.float32)
+        go = g["%d/go" % ci].view(np.float32).reshape(N, K, OH, OW)
+        tag = "%s case %d" % (build, ci)
+        assert_bits_equal(orc.conv2d_fp(x, w, b, st, pd, fused), g["%d/%s/fp" % (ci, build)], tag + " fp")
+        assert_bits_equal(orc.conv2d_bp(go, w, (H, W), st, pd, fused), g["%d/%s/bp" % (ci, build)], tag + " bp")
+        assert_bits_equal(orc.conv2d_wu(go, x, (R, S), st, pd, fused), g["%d/%s/wu" % (ci, build)], tag + " wu")
+    with pytest.raises(ValueError):
+        orc.conv2d_fp(np.zeros((1, 96, 4, 4), np.float32), np.zeros((8, 96, 1, 1), np.float32))
