@@ -168,6 +168,35 @@ def main():
                 modes[m] = round(8 * n / (a * 1e-3) / 1e9, 1)
             extras["modes_GB/s"] = modes
 
+        if rank == 0 and world == 1:
+            # per-channel rows kernel: 12 B/elem algorithmic (amax read + read + write)
+            xr = x[: 1 << 26]
+            yr = y[: 1 << 26]
+
+            def rows_step():
+                hip.quantize_rows_(xr, yr, 16384, fmt, rm, 448.0)
+
+            rows_step()
+            r_avg, _ = time_launches(rows_step, 10)
+            extras["rows_16384x4096"] = {"ms": round(r_avg, 5), "GB/s": round(12 * xr.numel() / (r_avg * 1e-3) / 1e9, 1)}
+
+            # cmodel emulated GEMM, BASELINE config 5's 8192^3: MFMA fmaf chain and VALU
+            # separate-rounding chain, each against its own roofline (fp32 MFMA 157.3 / VALU mul+add 78.6)
+            M = 8192
+            ga = torch.randn(M, M, device=dev)
+            gb = torch.randn(M, M, device=dev)
+            gc = torch.zeros(M, M, device=dev)
+            for name, variant, peak in (("gemm_8192_mfma_fma_chain", 1, 157.3), ("gemm_8192_valu_separate", 0, 78.6)):
+                def gstep(variant=variant):
+                    hip.gemm_(gc, ga, gb, 1.0, False, False, variant)
+
+                gstep()
+                g_avg, _ = time_launches(gstep, 5)
+                tf = 2.0 * M ** 3 / (g_avg * 1e-3) / 1e12
+                extras[name] = {"ms": round(g_avg, 4), "TFLOP/s": round(tf, 2), "peak": peak,
+                                "frac": round(tf / peak, 4)}
+            del ga, gb, gc
+
     if rank == 0 and world == 1 and not args.no_extras:
         import numpy as np
 

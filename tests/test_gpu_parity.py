@@ -334,3 +334,31 @@ def test_fused_per_tensor_small_and_large_paths_agree(hip, mode, n):
     s = orc.scale_from_amax(orc.amax(x), fmax)
     assert_bits_equal(o.cpu().numpy(), orc.cast(x, mode, scale=s, seed=5, offset=40), "%s n=%d" % (mode, n))
     assert ws.view(torch.float32).item() == float(orc.amax(x))
+
+
+def test_over_2g_elements_64bit_indexing(hip):
+    """BASELINE config 5's shard: 8 GiB fp32 = 2^31 elements per GPU, beyond the reference's `int size`.
+    In-place so that one 8.5 GiB buffer suffices; exact compare on windows at the start, across the 2^31
+    and 2^32-byte boundaries and at the ragged end, deterministic and stochastic."""
+    n = (1 << 31) + 4096 + 5
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.empty(n, device=DEV)
+    step = 1 << 28
+    for i in range(0, n, step):
+        m = min(step, n - i)
+        x[i:i + m] = torch.randn(m, device=DEV, generator=g) * torch.exp(torch.randn(m, device=DEV, generator=g) * 2)
+    wins = [(0, 5000), ((1 << 30) - 2500, 5000), ((1 << 31) - 2500, 5000), (n - 6000, 6000)]
+    keep = [x[a:a + b].cpu().numpy().copy() for a, b in wins]
+    for mode in ("E4M3_RNE", "E5M2_STOCHASTIC"):
+        fmt, rm = hip.parse_mode(mode)
+        y = x.clone() if mode == "E4M3_RNE" else x
+        hip.cast_(y, y, fmt, rm, scale=2.0, seed=17, offset=4)
+        torch.cuda.synchronize()
+        for (a, b), src in zip(wins, keep):
+            want = orc.cast(src, mode, scale=2.0, seed=17, offset=4, elem_base=a)
+            assert_bits_equal(y[a:a + b].cpu().numpy(), want, "%s window @%d" % (mode, a), nan_payload_ok=True)
+        ws = torch.zeros(1, dtype=torch.int32, device=DEV)
+        if mode == "E4M3_RNE":
+            hip.amax_(x, ws)
+            assert ws.view(torch.float32).item() == max(float(x[i:i + step].abs().max()) for i in range(0, n, step))
+        del y
