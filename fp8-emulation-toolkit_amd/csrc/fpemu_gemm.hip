@@ -46,7 +46,9 @@ struct Operand {
 };
 
 // Stage one BK x 128 tile (rows r0.., depth k0..) into registers: 2 x float4 per thread.
-template <bool KCONT>
+// FULL: the whole tile is inside the matrix and 16-byte loads are allowed (checked on the host): no
+// bounds tests in the loop.
+template <bool KCONT, bool FULL>
 __device__ __forceinline__ void tile_load(const Operand &X, int r0, int k0, int tid, f32x4 (&v)[2]) {
 #pragma unroll
   for (int h = 0; h < 2; h++) {
@@ -57,6 +59,11 @@ __device__ __forceinline__ void tile_load(const Operand &X, int r0, int k0, int 
     } else {                // thread -> (k, 4 consecutive rows)
       k = k0 + h * 8 + (tid >> 5);
       r = r0 + (tid & 31) * 4;
+    }
+    if constexpr (FULL) {
+      const float *src = KCONT ? X.p + (int64_t)r * X.ld + k : X.p + (int64_t)k * X.ld + r;
+      v[h] = *reinterpret_cast<const f32x4 *>(src);
+      continue;
     }
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
     if constexpr (KCONT) {
@@ -136,7 +143,7 @@ struct Batch {
 // CHAIN = false: acc starts at +0 and C = C + (alpha*acc + beta*C)      (simple_gemm, impl.cpp:226-231)
 // CHAIN = true : acc starts at C's current value and C = acc             (the conv kernels: MMEngine loads
 //                C, continues the chain and stores it back, simple_mm_engine.cpp:18-24)
-template <bool A_KCONT, bool B_KCONT, bool CHAIN>
+template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL>
 __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, float *C, int64_t ldc,
                                                        int c_vec, float alpha, float beta,
                                                        int tiles_m, int tiles_n, Batch bt) {
@@ -165,8 +172,8 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
     }
 
   f32x4 pa[2], pb[2];
-  tile_load<A_KCONT>(A, m0, 0, tid, pa);
-  tile_load<B_KCONT>(B, n0, 0, tid, pb);
+  tile_load<A_KCONT, FULL>(A, m0, 0, tid, pa);
+  tile_load<B_KCONT, FULL>(B, n0, 0, tid, pb);
   tile_store<A_KCONT>(As[0], tid, pa);
   tile_store<B_KCONT>(Bs[0], tid, pb);
   __syncthreads();
@@ -175,8 +182,8 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
   for (int k0 = 0; k0 < K; k0 += BK) {
     const bool more = k0 + BK < K;
     if (more) {
-      tile_load<A_KCONT>(A, m0, k0 + BK, tid, pa);
-      tile_load<B_KCONT>(B, n0, k0 + BK, tid, pb);
+      tile_load<A_KCONT, FULL>(A, m0, k0 + BK, tid, pa);
+      tile_load<B_KCONT, FULL>(B, n0, k0 + BK, tid, pb);
     }
     const float *as = As[cur], *bs = Bs[cur];
 #pragma unroll 2
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 // 128x128 tile as 2x2 MFMA 32x32 tiles.  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5]
 // and B[k = l>>5][j = l&31]; D[reg]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 // ---------------------------------------------------------------------------------------------
-template <bool A_KCONT, bool B_KCONT, bool CHAIN>
+template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL>
 __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
                                                        float alpha, float beta, int tiles_m, int tiles_n,
                                                        Batch bt) {
@@ -270,8 +277,8 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
       }
 
   f32x4 pa[2], pb[2];
-  tile_load<A_KCONT>(A, m0, 0, tid, pa);
-  tile_load<B_KCONT>(B, n0, 0, tid, pb);
+  tile_load<A_KCONT, FULL>(A, m0, 0, tid, pa);
+  tile_load<B_KCONT, FULL>(B, n0, 0, tid, pb);
   tile_store<A_KCONT>(As[0], tid, pa);
   tile_store<B_KCONT>(Bs[0], tid, pb);
   __syncthreads();
@@ -280,22 +287,33 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
   for (int k0 = 0; k0 < K; k0 += BK) {
     const bool more = k0 + BK < K;
     if (more) {
-      tile_load<A_KCONT>(A, m0, k0 + BK, tid, pa);
-      tile_load<B_KCONT>(B, n0, k0 + BK, tid, pb);
+      tile_load<A_KCONT, FULL>(A, m0, k0 + BK, tid, pa);
+      tile_load<B_KCONT, FULL>(B, n0, k0 + BK, tid, pb);
     }
-    const float *as = As[cur], *bs = Bs[cur];
+    const float *as = As[cur] + lk * LDT + wm + li, *bs = Bs[cur] + lk * LDT + wn + li;
+    // operand fragments one k-pair ahead of the MFMAs that consume them (register double buffer), so the
+    // LDS latency of step s+1 runs under the four MFMAs of step s
+    float a[2][2], b[2][2];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[2], b[2];
+    for (int i = 0; i < 2; i++) a[0][i] = as[i * 32];
 #pragma unroll
-      for (int i = 0; i < 2; i++) a[i] = as[(kk + lk) * LDT + wm + i * 32 + li];
+    for (int j = 0; j < 2; j++) b[0][j] = bs[j * 32];
 #pragma unroll
-      for (int j = 0; j < 2; j++) b[j] = bs[(kk + lk) * LDT + wn + j * 32 + li];
+    for (int st = 0; st < BK / 2; st++) {
+      const int c = st & 1;
+      if (st + 1 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) a[c ^ 1][i] = as[(st + 1) * 2 * LDT + i * 32];
+#pragma unroll
+        for (int j = 0; j < 2; j++) b[c ^ 1][j] = bs[(st + 1) * 2 * LDT + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads of step st+1 ahead of the MFMAs of step st
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
       tile_store<A_KCONT>(As[cur ^ 1], tid, pa);
@@ -306,20 +324,42 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
   }
 
   const int M = A.R, N = B.R;
+  if constexpr (CHAIN) {
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+      for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int col = n0 + wn + j * 32 + li;
-        if (row < M && col < N) {
-          float *dst = C + (int64_t)row * ldc + col;
-          if constexpr (CHAIN) *dst = acc[i][j][r];
-          else *dst = epilogue(*dst, acc[i][j][r], alpha, beta);
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int col = n0 + wn + j * 32 + li;
+          if (FULL || (row < M && col < N)) C[(int64_t)row * ldc + col] = acc[i][j][r];
         }
-      }
+  } else {
+    // all 64 reads of C first (independent), then the read-modify-writes: one memory round trip, not 64
+    f32x16 cin[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int col = n0 + wn + j * 32 + li;
+          cin[i][j][r] = (FULL || (row < M && col < N)) ? C[(int64_t)row * ldc + col] : 0.f;
+        }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int col = n0 + wn + j * 32 + li;
+          if (FULL || (row < M && col < N))
+            C[(int64_t)row * ldc + col] = epilogue(cin[i][j][r], acc[i][j][r], alpha, beta);
+        }
+  }
 }
 
 typedef void (*seqk_fn)(Operand, Operand, float *, int64_t, int, float, float, int, int, Batch);
@@ -327,13 +367,13 @@ typedef void (*mfma_fn)(Operand, Operand, float *, int64_t, float, float, int, i
 
 bool aligned16(const void *p) { return ((uintptr_t)p % 16u) == 0; }
 
-template <bool CHAIN> seqk_fn pick_seqk(bool a_kcont, bool b_kcont) {
-  return a_kcont ? (b_kcont ? gemm_seqk_kernel<true, true, CHAIN> : gemm_seqk_kernel<true, false, CHAIN>)
-                 : (b_kcont ? gemm_seqk_kernel<false, true, CHAIN> : gemm_seqk_kernel<false, false, CHAIN>);
+template <bool CHAIN, bool FULL> seqk_fn pick_seqk(bool a_kcont, bool b_kcont) {
+  return a_kcont ? (b_kcont ? gemm_seqk_kernel<true, true, CHAIN, FULL> : gemm_seqk_kernel<true, false, CHAIN, FULL>)
+                 : (b_kcont ? gemm_seqk_kernel<false, true, CHAIN, FULL> : gemm_seqk_kernel<false, false, CHAIN, FULL>);
 }
-template <bool CHAIN> mfma_fn pick_mfma(bool a_kcont, bool b_kcont) {
-  return a_kcont ? (b_kcont ? gemm_mfma_kernel<true, true, CHAIN> : gemm_mfma_kernel<true, false, CHAIN>)
-                 : (b_kcont ? gemm_mfma_kernel<false, true, CHAIN> : gemm_mfma_kernel<false, false, CHAIN>);
+template <bool CHAIN, bool FULL> mfma_fn pick_mfma(bool a_kcont, bool b_kcont) {
+  return a_kcont ? (b_kcont ? gemm_mfma_kernel<true, true, CHAIN, FULL> : gemm_mfma_kernel<true, false, CHAIN, FULL>)
+                 : (b_kcont ? gemm_mfma_kernel<false, true, CHAIN, FULL> : gemm_mfma_kernel<false, false, CHAIN, FULL>);
 }
 
 int launch_gemm(const char *who, float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
@@ -364,13 +404,17 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   const int64_t nwg = (int64_t)tiles_m * tiles_n;
   if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "too many tiles");
   const float beta = 0.0f;  // simple_gemm.cpp:58
+  // every tile whole and 16-byte loads everywhere: the kernels drop their bounds tests
+  const bool full = a.vec && b.vec && (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && K > 0;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)nwg, (unsigned)batch);
   if (variant == 0) {
-    seqk_fn fn = chain ? pick_seqk<true>(a_kcont, b_kcont) : pick_seqk<false>(a_kcont, b_kcont);
+    seqk_fn fn = chain ? (full ? pick_seqk<true, true>(a_kcont, b_kcont) : pick_seqk<true, false>(a_kcont, b_kcont))
+                       : (full ? pick_seqk<false, true>(a_kcont, b_kcont) : pick_seqk<false, false>(a_kcont, b_kcont));
     hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, c_vec, alpha, beta, tiles_m, tiles_n, bt);
   } else if (variant == 1) {
-    mfma_fn fn = chain ? pick_mfma<true>(a_kcont, b_kcont) : pick_mfma<false>(a_kcont, b_kcont);
+    mfma_fn fn = chain ? (full ? pick_mfma<true, true>(a_kcont, b_kcont) : pick_mfma<true, false>(a_kcont, b_kcont))
+                       : (full ? pick_mfma<false, true>(a_kcont, b_kcont) : pick_mfma<false, false>(a_kcont, b_kcont));
     hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);
   } else {
     return fail(FPEMU_EINVAL, "unknown variant");

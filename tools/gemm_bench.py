@@ -30,9 +30,12 @@ def run(M, N, K, at, bt, variant, iters=5):
 
 if __name__ == "__main__":
     sizes = [(4096, 4096, 4096), (8192, 8192, 8192)]
-    if len(sys.argv) > 1:
-        sizes = [tuple(int(v) for v in s.split("x")) for s in sys.argv[1:]]
-    for v in (1, 0):
+    args = [a for a in sys.argv[1:] if "x" in a]
+    if args:
+        sizes = [tuple(int(v) for v in s.split("x")) for s in args]
+    variants = (1,) if "v1" in sys.argv else (0,) if "v0" in sys.argv else (1, 0)
+    trans = ((False, False),) if "nn" in sys.argv else ((False, False), (False, True), (True, False), (True, True))
+    for v in variants:
         for (M, N, K) in sizes:
-            for at, bt in ((False, False), (False, True), (True, False), (True, True)):
+            for at, bt in trans:
                 run(M, N, K, at, bt, v)
