@@ -336,29 +336,27 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
           if (FULL || (row < M && col < N)) C[(int64_t)row * ldc + col] = acc[i][j][r];
         }
   } else {
-    // all 64 reads of C first (independent), then the read-modify-writes: one memory round trip, not 64
-    f32x16 cin[2][2];
+    // per 32x32 MFMA tile: its 16 reads of C first (independent), then the 16 read-modify-writes -- four
+    // memory round trips per lane instead of 64, without holding all of C in registers
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 2; j++)
+      for (int j = 0; j < 2; j++) {
+        f32x16 cin;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int col = n0 + wn + j * 32 + li;
-          cin[i][j][r] = (FULL || (row < M && col < N)) ? C[(int64_t)row * ldc + col] : 0.f;
+          cin[r] = (FULL || (row < M && col < N)) ? C[(int64_t)row * ldc + col] : 0.f;
         }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int col = n0 + wn + j * 32 + li;
           if (FULL || (row < M && col < N))
-            C[(int64_t)row * ldc + col] = epilogue(cin[i][j][r], acc[i][j][r], alpha, beta);
+            C[(int64_t)row * ldc + col] = epilogue(cin[r], acc[i][j][r], alpha, beta);
         }
+      }
   }
 }
 
