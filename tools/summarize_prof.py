@@ -34,6 +34,20 @@ with open("profiles/%s_kernel_stats.md" % tag, "w") as f:
         f.write("| `%s` | %d | %.1f | %.1f | %.1f | %.2f |\n" % (r["kernel"], r["calls"], r["avg_ns"] / 1e3,
                                                                 r["min_ns"] / 1e3, r["max_ns"] / 1e3, r["pct"]))
 
+gstats = glob.glob(os.path.join(src, "gemm_stats", "*", "*_kernel_stats.csv"))
+if gstats:
+    with open("profiles/%s_gemm_kernel_stats.md" % tag, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 tools/gemm_bench.py 8192x8192x8192 nn\n\n")
+        f.write("2 * 8192^3 = 1.0995e12 FLOP per launch\n\n")
+        f.write("| kernel | calls | avg ms | min ms | TFLOP/s at avg |\n|---|---|---|---|---|\n")
+        for r in csv.DictReader(open(gstats[0])):
+            if "gemm_" not in r["Name"]:
+                continue
+            avg = float(r["AverageNs"])
+            f.write("| `%s` | %d | %.3f | %.3f | %.1f |\n" % (short(r["Name"]), int(r["Calls"]), avg / 1e6,
+                                                              int(r["MinNs"]) / 1e6, 2 * 8192.0 ** 3 / avg / 1e3))
+    print(open("profiles/%s_gemm_kernel_stats.md" % tag).read())
+
 pmc = {}
 for which, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     files = glob.glob(os.path.join(src, which, "*", "*_counter_collection.csv"))
