@@ -31,7 +31,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BM = 128, BN = 128, BK = 16;  // BK: k-depth of the VALU kernel's tiles
+constexpr int MBK = 32;                     // k-depth of the MFMA kernel's tiles (half the barriers)
 constexpr int LDT = 132;  // LDS row stride in floats (pad 4: 2-way instead of 4-way write conflicts)
 constexpr int NT = 256;
 
@@ -45,17 +46,17 @@ struct Operand {
   int vec;      // 16-byte loads allowed (alignment + extents checked on the host)
 };
 
-// Stage one BK x 128 tile (rows r0.., depth k0..) into registers: 2 x float4 per thread.
+// Stage one TBK x 128 tile (rows r0.., depth k0..) into registers: TBK/8 float4 per thread.
 // FULL: the whole tile is inside the matrix and 16-byte loads are allowed (checked on the host): no
 // bounds tests in the loop.
-template <bool KCONT, bool FULL>
-__device__ __forceinline__ void tile_load(const Operand &X, int r0, int k0, int tid, f32x4 (&v)[2]) {
+template <bool KCONT, bool FULL, int TBK>
+__device__ __forceinline__ void tile_load(const Operand &X, int r0, int k0, int tid, f32x4 (&v)[TBK / 8]) {
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
+  for (int h = 0; h < TBK / 8; h++) {
     int r, k;
     if constexpr (KCONT) {  // thread -> (row, 4 consecutive k)
-      r = r0 + h * 64 + (tid >> 2);
-      k = k0 + (tid & 3) * 4;
+      r = r0 + (h & 1) * 64 + (tid >> 2);
+      k = k0 + (h >> 1) * 16 + (tid & 3) * 4;
     } else {                // thread -> (k, 4 consecutive rows)
       k = k0 + h * 8 + (tid >> 5);
       r = r0 + (tid & 31) * 4;
@@ -94,12 +95,12 @@ __device__ __forceinline__ void tile_load(const Operand &X, int r0, int k0, int 
 }
 
 // Registers -> LDS image T[k][r] (k-major, row stride LDT).
-template <bool KCONT>
-__device__ __forceinline__ void tile_store(float *T, int tid, const f32x4 (&v)[2]) {
+template <bool KCONT, int TBK>
+__device__ __forceinline__ void tile_store(float *T, int tid, const f32x4 (&v)[TBK / 8]) {
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
+  for (int h = 0; h < TBK / 8; h++) {
     if constexpr (KCONT) {
-      const int r = h * 64 + (tid >> 2), k = (tid & 3) * 4;
+      const int r = (h & 1) * 64 + (tid >> 2), k = (h >> 1) * 16 + (tid & 3) * 4;
 #pragma unroll
       for (int c = 0; c < 4; c++) T[(k + c) * LDT + r] = v[h][c];
     } else {
@@ -172,18 +173,18 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
     }
 
   f32x4 pa[2], pb[2];
-  tile_load<A_KCONT, FULL>(A, m0, 0, tid, pa);
-  tile_load<B_KCONT, FULL>(B, n0, 0, tid, pb);
-  tile_store<A_KCONT>(As[0], tid, pa);
-  tile_store<B_KCONT>(Bs[0], tid, pb);
+  tile_load<A_KCONT, FULL, BK>(A, m0, 0, tid, pa);
+  tile_load<B_KCONT, FULL, BK>(B, n0, 0, tid, pb);
+  tile_store<A_KCONT, BK>(As[0], tid, pa);
+  tile_store<B_KCONT, BK>(Bs[0], tid, pb);
   __syncthreads();
 
   int cur = 0;
   for (int k0 = 0; k0 < K; k0 += BK) {
     const bool more = k0 + BK < K;
     if (more) {
-      tile_load<A_KCONT, FULL>(A, m0, k0 + BK, tid, pa);
-      tile_load<B_KCONT, FULL>(B, n0, k0 + BK, tid, pb);
+      tile_load<A_KCONT, FULL, BK>(A, m0, k0 + BK, tid, pa);
+      tile_load<B_KCONT, FULL, BK>(B, n0, k0 + BK, tid, pb);
     }
     const float *as = As[cur], *bs = Bs[cur];
 #pragma unroll 2
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
         }
     }
     if (more) {
-      tile_store<A_KCONT>(As[cur ^ 1], tid, pa);
-      tile_store<B_KCONT>(Bs[cur ^ 1], tid, pb);
+      tile_store<A_KCONT, BK>(As[cur ^ 1], tid, pa);
+      tile_store<B_KCONT, BK>(Bs[cur ^ 1], tid, pb);
     }
     __syncthreads();
     cur ^= 1;
@@ -251,8 +252,8 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
   A.p += (int64_t)blockIdx.y * bt.sa;
   B.p += (int64_t)blockIdx.y * bt.sb;
   C += (int64_t)blockIdx.y * bt.sc;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float As[2][MBK * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][MBK * LDT];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int tm, tn;
   tile_of_block(tiles_m, tiles_n, tm, tn);
@@ -276,19 +277,19 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
         }
       }
 
-  f32x4 pa[2], pb[2];
-  tile_load<A_KCONT, FULL>(A, m0, 0, tid, pa);
-  tile_load<B_KCONT, FULL>(B, n0, 0, tid, pb);
-  tile_store<A_KCONT>(As[0], tid, pa);
-  tile_store<B_KCONT>(Bs[0], tid, pb);
+  f32x4 pa[MBK / 8], pb[MBK / 8];
+  tile_load<A_KCONT, FULL, MBK>(A, m0, 0, tid, pa);
+  tile_load<B_KCONT, FULL, MBK>(B, n0, 0, tid, pb);
+  tile_store<A_KCONT, MBK>(As[0], tid, pa);
+  tile_store<B_KCONT, MBK>(Bs[0], tid, pb);
   __syncthreads();
 
   int cur = 0;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    const bool more = k0 + BK < K;
+  for (int k0 = 0; k0 < K; k0 += MBK) {
+    const bool more = k0 + MBK < K;
     if (more) {
-      tile_load<A_KCONT, FULL>(A, m0, k0 + BK, tid, pa);
-      tile_load<B_KCONT, FULL>(B, n0, k0 + BK, tid, pb);
+      tile_load<A_KCONT, FULL, MBK>(A, m0, k0 + MBK, tid, pa);
+      tile_load<B_KCONT, FULL, MBK>(B, n0, k0 + MBK, tid, pb);
     }
     const float *as = As[cur] + lk * LDT + wm + li, *bs = Bs[cur] + lk * LDT + wn + li;
     // operand fragments one k-pair ahead of the MFMAs that consume them (register double buffer), so the
@@ -299,9 +300,9 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
 #pragma unroll
     for (int j = 0; j < 2; j++) b[0][j] = bs[j * 32];
 #pragma unroll
-    for (int st = 0; st < BK / 2; st++) {
+    for (int st = 0; st < MBK / 2; st++) {
       const int c = st & 1;
-      if (st + 1 < BK / 2) {
+      if (st + 1 < MBK / 2) {
 #pragma unroll
         for (int i = 0; i < 2; i++) a[c ^ 1][i] = as[(st + 1) * 2 * LDT + i * 32];
 #pragma unroll
@@ -316,8 +317,8 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
-      tile_store<A_KCONT>(As[cur ^ 1], tid, pa);
-      tile_store<B_KCONT>(Bs[cur ^ 1], tid, pb);
+      tile_store<A_KCONT, MBK>(As[cur ^ 1], tid, pa);
+      tile_store<B_KCONT, MBK>(Bs[cur ^ 1], tid, pb);
     }
     __syncthreads();
     cur ^= 1;
@@ -403,7 +404,7 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "too many tiles");
   const float beta = 0.0f;  // simple_gemm.cpp:58
   // every tile whole and 16-byte loads everywhere: the kernels drop their bounds tests
-  const bool full = a.vec && b.vec && (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && K > 0;
+  const bool full = a.vec && b.vec && (M % BM == 0) && (N % BN == 0) && (K % (variant == 1 ? MBK : BK) == 0) && K > 0;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)nwg, (unsigned)batch);
   if (variant == 0) {
