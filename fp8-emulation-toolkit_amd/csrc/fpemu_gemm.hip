@@ -28,6 +28,7 @@ extern "C" void fpemu_set_error_(const char *msg);  // fpemu_hip.hip: thread-loc
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -160,16 +161,17 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
   const int ty = tid >> 4, tx = tid & 15;  // lane owns rows {ty*4.., 64+ty*4..} x cols {tx*4.., 64+tx*4..}
   const int K = A.K;
 
-  float acc[8][8];
+  f32x2 acc2[8][4];  // acc2[i][j] = outputs (i, 2j) and (i, 2j+1)
 #pragma unroll
   for (int i = 0; i < 8; i++)
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      acc[i][j] = 0.f;
+      float v = 0.f;
       if constexpr (CHAIN) {
         const int r = m0 + (i >> 2) * 64 + ty * 4 + (i & 3), c = n0 + (j >> 2) * 64 + tx * 4 + (j & 3);
-        if (r < A.R && c < B.R) acc[i][j] = C[(int64_t)r * ldc + c];
+        if (r < A.R && c < B.R) v = C[(int64_t)r * ldc + c];
       }
+      acc2[i][j >> 1][j & 1] = v;
     }
 
   f32x4 pa[2], pb[2];
@@ -194,14 +196,19 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
       const f32x4 b0 = *reinterpret_cast<const f32x4 *>(&bs[kk * LDT + tx * 4]);
       const f32x4 b1 = *reinterpret_cast<const f32x4 *>(&bs[kk * LDT + 64 + tx * 4]);
       const float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      const float b[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      const f32x2 b2[4] = {{b0[0], b0[1]}, {b0[2], b0[3]}, {b1[0], b1[1]}, {b1[2], b1[3]}};
+      // explicit 2-wide form so that every multiply and every add is a packed instruction
+      // (v_pk_mul_f32 / v_pk_add_f32: two lanes of the chain per issue slot; left to the SLP
+      // vectoriser half of the adds stayed scalar)
 #pragma unroll
-      for (int i = 0; i < 8; i++)
+      for (int i = 0; i < 8; i++) {
+        const f32x2 ai = {a[i], a[i]};
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const float p = a[i] * b[j];  // rounded product: its own value (contraction is off)
-          acc[i][j] = acc[i][j] + p;    // k ascending, one add per step
+        for (int j = 0; j < 4; j++) {
+          const f32x2 p = ai * b2[j];      // rounded products: values of their own (contraction is off)
+          acc2[i][j] = acc2[i][j] + p;     // k ascending, one add per step
         }
+      }
     }
     if (more) {
       tile_store<A_KCONT, BK>(As[cur ^ 1], tid, pa);
@@ -225,16 +232,16 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
         if constexpr (CHAIN) {
 #pragma unroll
           for (int jj = 0; jj < 4; jj++)
-            if (c + jj < N) dst[jj] = acc[ih * 4 + ii][jh * 4 + jj];
+            if (c + jj < N) dst[jj] = acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1];
         } else if (c_vec && c + 3 < N) {
           f32x4 ci = *reinterpret_cast<const f32x4 *>(dst), o;
 #pragma unroll
-          for (int jj = 0; jj < 4; jj++) o[jj] = epilogue(ci[jj], acc[ih * 4 + ii][jh * 4 + jj], alpha, beta);
+          for (int jj = 0; jj < 4; jj++) o[jj] = epilogue(ci[jj], acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1], alpha, beta);
           *reinterpret_cast<f32x4 *>(dst) = o;
         } else {
 #pragma unroll
           for (int jj = 0; jj < 4; jj++)
-            if (c + jj < N) dst[jj] = epilogue(dst[jj], acc[ih * 4 + ii][jh * 4 + jj], alpha, beta);
+            if (c + jj < N) dst[jj] = epilogue(dst[jj], acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1], alpha, beta);
         }
       }
     }
