@@ -16,7 +16,7 @@
 // MFMA or separate roundings on the VALU, C = acc) over operands laid out in that order:
 //   fp: out[n]  (K x P)      = chain(bias rows;  Wfp (K x CRS)    @ cols[n]  (CRS x P))     batched over n
 //   bp: gin[n]  (C x HW)     = chain(0;          Wbp (C x KRS)    @ colsb[n] (KRS x HW))    batched over n
-//   wu: Gw      (K x CRS)    = chain(Gw;         gout[n] (K x P)  @ cols[n]^T (P x CRS))    n = 0, 1, ...
+//   wu: Gw      (K x CRS)    = chain(Gw;         gout[n] (K x P)  @ cols[n]^T (P x CRS))    k segments n = 0, 1, ...
 // cols / colsb are gathered by the kernels below (zero for padding taps: the reference multiplies its
 // zero padding in as well; for bp taps that do not exist for a pixel contribute w * 0, which leaves a
 // chain that started at +0 unchanged for every finite w).  Everything here is HBM-bound gather work;
@@ -205,10 +205,6 @@ int64_t chunk_images(const Geo &g, int64_t per_img, int64_t avail_floats) {
 
 extern "C" {
 
-int fpemu_gemm_chain_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
-                         int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans, int variant,
-                         int64_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, void *stream);
-
 uint64_t fpemu_conv2d_workspace_bytes(int kind, int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
                                       int64_t R, int64_t S, int64_t stride, int64_t pad) {
   Geo g;
@@ -248,7 +244,7 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
     hipLaunchKernelGGL(cols_fp, dim3(blocks_for(nb * crs * P)), dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_f32(out + n0 * K * P, Wm, cols, K, P, crs, crs, P, P, 0, 0, variant, nb, 0, crs * P,
-                              K * P, stream);
+                              K * P, 1, 0, 0, stream);
     if (rc != FPEMU_OK) return rc;
   }
   return FPEMU_OK;
@@ -280,7 +276,7 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
     hipLaunchKernelGGL(cols_bp, dim3(blocks_for(nb * krs * HW)), dim3(NT), 0, s, gout + n0 * K * P, cols, g, nb);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_f32(gin + n0 * C * HW, Wm, cols, C, HW, krs, krs, HW, HW, 0, 0, variant, nb, 0, krs * HW,
-                              C * HW, stream);
+                              C * HW, 1, 0, 0, stream);
     if (rc != FPEMU_OK) return rc;
   }
   return FPEMU_OK;
@@ -309,11 +305,10 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
     hipLaunchKernelGGL(cols_fp, dim3(blocks_for(nb * crs * P)), dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb);
     CHECK_LAUNCH(who);
-    for (int64_t n = 0; n < nb; n++) {  // one chain across images: launches in image order on one stream
-      rc = fpemu_gemm_chain_f32(Gm, gout + (n0 + n) * K * P, cols + n * crs * P, K, crs, P, P, P, crs, 0, 1,
-                                variant, 1, 0, 0, 0, stream);
-      if (rc != FPEMU_OK) return rc;
-    }
+    // one chain across the chunk's images in ONE launch: k segments = images (chunks follow in order)
+    rc = fpemu_gemm_chain_f32(Gm, gout + n0 * K * P, cols, K, crs, P, P, P, crs, 0, 1, variant, 1, 0, 0, 0, nb,
+                              K * P, crs * P, stream);
+    if (rc != FPEMU_OK) return rc;
   }
   hipLaunchKernelGGL(unpack_gw, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, gw, g);
   CHECK_LAUNCH(who);

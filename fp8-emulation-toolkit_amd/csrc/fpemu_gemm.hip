@@ -32,10 +32,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;  // BK: k-depth of the VALU kernel's tiles
+constexpr int BM = 128, BN = 128, BK = 16;  // VALU kernel: 128 x 128 x 16 tiles
 constexpr int MBK = 32;                     // k-depth of the MFMA kernel's tiles (half the barriers)
-constexpr int LDT = 132;  // LDS row stride in floats (pad 4: 2-way instead of 4-way write conflicts)
 constexpr int NT = 256;
+// LDS images are k-major, T[k][r], row stride ROWS + 4 floats (2-way instead of 4-way write conflicts;
+// a 2-way ds_write_b32 conflict is free)
+template <int ROWS> constexpr int ldt() { return ROWS + 4; }
 
 // Operand view: element (r, k) of op(X) with r the M (or N) index.
 //   KCONT = true : memory is [R][K] row-major (k contiguous)   -> A not transposed, B transposed
@@ -47,30 +49,40 @@ struct Operand {
   int vec;      // 16-byte loads allowed (alignment + extents checked on the host)
 };
 
-// Stage one TBK x 128 tile (rows r0.., depth k0..) into registers: TBK/8 float4 per thread.
+// Stage one TBK x ROWS tile (rows r0.., depth k0..) into registers: TBK*ROWS/1024 float4 per thread.
 // FULL: the whole tile is inside the matrix and 16-byte loads are allowed (checked on the host): no
 // bounds tests in the loop.
-template <bool KCONT, bool FULL, int TBK>
-__device__ __forceinline__ void tile_load(const Operand &X, int r0, int k0, int tid, f32x4 (&v)[TBK / 8]) {
+template <bool KCONT, int TBK, int ROWS>
+__device__ __forceinline__ void tile_coords(int h, int tid, int &r, int &k) {
+  if constexpr (KCONT) {  // thread -> (row, 4 consecutive k): 4 threads per row, 64 rows per pass
+    constexpr int RP = ROWS / 64;
+    r = (h % RP) * 64 + (tid >> 2);
+    k = (h / RP) * 16 + (tid & 3) * 4;
+  } else {                // thread -> (k, 4 consecutive rows): ROWS/4 threads per k
+    constexpr int TPR = ROWS / 4, KPP = NT / TPR;
+    k = h * KPP + tid / TPR;
+    r = (tid % TPR) * 4;
+  }
+}
+
+template <bool KCONT, bool FULL, int TBK, int ROWS>
+__device__ __forceinline__ void tile_load(const Operand &X, const float *base, int r0, int k0, int tid,
+                                          f32x4 (&v)[TBK * ROWS / 1024]) {
 #pragma unroll
-  for (int h = 0; h < TBK / 8; h++) {
+  for (int h = 0; h < TBK * ROWS / 1024; h++) {
     int r, k;
-    if constexpr (KCONT) {  // thread -> (row, 4 consecutive k)
-      r = r0 + (h & 1) * 64 + (tid >> 2);
-      k = k0 + (h >> 1) * 16 + (tid & 3) * 4;
-    } else {                // thread -> (k, 4 consecutive rows)
-      k = k0 + h * 8 + (tid >> 5);
-      r = r0 + (tid & 31) * 4;
-    }
+    tile_coords<KCONT, TBK, ROWS>(h, tid, r, k);
+    r += r0;
+    k += k0;
     if constexpr (FULL) {
-      const float *src = KCONT ? X.p + (int64_t)r * X.ld + k : X.p + (int64_t)k * X.ld + r;
+      const float *src = KCONT ? base + (int64_t)r * X.ld + k : base + (int64_t)k * X.ld + r;
       v[h] = *reinterpret_cast<const f32x4 *>(src);
       continue;
     }
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
     if constexpr (KCONT) {
       if (r < X.R) {
-        const float *src = X.p + (int64_t)r * X.ld + k;
+        const float *src = base + (int64_t)r * X.ld + k;
         if (X.vec && k + 3 < X.K) {
           t = *reinterpret_cast<const f32x4 *>(src);
         } else {
@@ -81,7 +93,7 @@ __device__ __forceinline__ void tile_load(const Operand &X, int r0, int k0, int 
       }
     } else {
       if (k < X.K) {
-        const float *src = X.p + (int64_t)k * X.ld + r;
+        const float *src = base + (int64_t)k * X.ld + r;
         if (X.vec && r + 3 < X.R) {
           t = *reinterpret_cast<const f32x4 *>(src);
         } else {
@@ -95,18 +107,19 @@ __device__ __forceinline__ void tile_load(const Operand &X, int r0, int k0, int 
   }
 }
 
-// Registers -> LDS image T[k][r] (k-major, row stride LDT).
-template <bool KCONT, int TBK>
-__device__ __forceinline__ void tile_store(float *T, int tid, const f32x4 (&v)[TBK / 8]) {
+// Registers -> LDS image T[k][r].
+template <bool KCONT, int TBK, int ROWS>
+__device__ __forceinline__ void tile_store(float *T, int tid, const f32x4 (&v)[TBK * ROWS / 1024]) {
+  constexpr int LD = ldt<ROWS>();
 #pragma unroll
-  for (int h = 0; h < TBK / 8; h++) {
+  for (int h = 0; h < TBK * ROWS / 1024; h++) {
+    int r, k;
+    tile_coords<KCONT, TBK, ROWS>(h, tid, r, k);
     if constexpr (KCONT) {
-      const int r = (h & 1) * 64 + (tid >> 2), k = (h >> 1) * 16 + (tid & 3) * 4;
 #pragma unroll
-      for (int c = 0; c < 4; c++) T[(k + c) * LDT + r] = v[h][c];
+      for (int c = 0; c < 4; c++) T[(k + c) * LD + r] = v[h][c];
     } else {
-      const int k = h * 8 + (tid >> 5), r = (tid & 31) * 4;
-      *reinterpret_cast<f32x4 *>(&T[k * LDT + r]) = v[h];
+      *reinterpret_cast<f32x4 *>(&T[k * LD + r]) = v[h];
     }
   }
 }
@@ -138,8 +151,13 @@ __device__ __forceinline__ float epilogue(float c_in, float acc, float alpha, fl
 }
 
 // Batch: blockIdx.y selects the problem; operands advance by their batch strides (0 = shared).
+// k segments: the k loop runs nseg times over K, A and B advancing by ka / kb elements each time, all
+// into the same accumulators -- one chain over nseg*K products (the conv weight update chains image
+// after image, simple_conv2d_impl.cpp:645-667).
 struct Batch {
   int64_t sa, sb, sc;
+  int64_t ka, kb;
+  int nseg;
 };
 
 // CHAIN = false: acc starts at +0 and C = C + (alpha*acc + beta*C)      (simple_gemm, impl.cpp:226-231)
@@ -152,8 +170,8 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
   A.p += (int64_t)blockIdx.y * bt.sa;
   B.p += (int64_t)blockIdx.y * bt.sb;
   C += (int64_t)blockIdx.y * bt.sc;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * ldt<BM>()];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * ldt<BN>()];
   const int tid = threadIdx.x;
   int tm, tn;
   tile_of_block(tiles_m, tiles_n, tm, tn);
@@ -174,19 +192,29 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
       acc2[i][j >> 1][j & 1] = v;
     }
 
+  constexpr int LDT = ldt<BM>();
   f32x4 pa[2], pb[2];
-  tile_load<A_KCONT, FULL, BK>(A, m0, 0, tid, pa);
-  tile_load<B_KCONT, FULL, BK>(B, n0, 0, tid, pb);
-  tile_store<A_KCONT, BK>(As[0], tid, pa);
-  tile_store<B_KCONT, BK>(Bs[0], tid, pb);
+  const float *abase = A.p, *bbase = B.p;
+  tile_load<A_KCONT, FULL, BK, BM>(A, abase, m0, 0, tid, pa);
+  tile_load<B_KCONT, FULL, BK, BN>(B, bbase, n0, 0, tid, pb);
+  tile_store<A_KCONT, BK, BM>(As[0], tid, pa);
+  tile_store<B_KCONT, BK, BN>(Bs[0], tid, pb);
   __syncthreads();
 
   int cur = 0;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    const bool more = k0 + BK < K;
+  const int kt = (K + BK - 1) / BK, total = kt * bt.nseg;
+  int nk0 = 0;  // k offset of the tile being prefetched
+  for (int it = 0; it < total; it++) {
+    const bool more = it + 1 < total;
     if (more) {
-      tile_load<A_KCONT, FULL, BK>(A, m0, k0 + BK, tid, pa);
-      tile_load<B_KCONT, FULL, BK>(B, n0, k0 + BK, tid, pb);
+      nk0 += BK;
+      if (nk0 >= K) {  // next k segment
+        nk0 = 0;
+        abase += bt.ka;
+        bbase += bt.kb;
+      }
+      tile_load<A_KCONT, FULL, BK, BM>(A, abase, m0, nk0, tid, pa);
+      tile_load<B_KCONT, FULL, BK, BN>(B, bbase, n0, nk0, tid, pb);
     }
     const float *as = As[cur], *bs = Bs[cur];
 #pragma unroll 2
@@ -211,8 +239,8 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
       }
     }
     if (more) {
-      tile_store<A_KCONT, BK>(As[cur ^ 1], tid, pa);
-      tile_store<B_KCONT, BK>(Bs[cur ^ 1], tid, pb);
+      tile_store<A_KCONT, BK, BM>(As[cur ^ 1], tid, pa);
+      tile_store<B_KCONT, BK, BN>(Bs[cur ^ 1], tid, pb);
     }
     __syncthreads();
     cur ^= 1;
@@ -248,14 +276,19 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 }
 
 // ---------------------------------------------------------------------------------------------
-// MFMA fp32-accumulate variant.  4 waves per block, wave w owns the 64x64 quadrant (w>>1, w&1) of a
-// 128x128 tile as 2x2 MFMA 32x32 tiles.  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5]
-// and B[k = l>>5][j = l&31]; D[reg]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// MFMA variant.  4 waves per block in a 2 x 2 grid; wave w owns a (32 TW) x (32 TW) quadrant as TW x TW
+// MFMA 32x32 tiles: TW = 2 -> 128 x 128 block tiles (large problems), TW = 1 -> 64 x 64 block tiles
+// (problems that would not fill the chip with 128 x 128 tiles: a chain cannot be split along k, so small
+// M x N needs small tiles to spread over CUs).  v_mfma_f32_32x32x2_f32: lane l supplies
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; D[reg]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 // ---------------------------------------------------------------------------------------------
-template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL>
+template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL, int TW>
 __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
                                                        float alpha, float beta, int tiles_m, int tiles_n,
                                                        Batch bt) {
+  constexpr int TB = 64 * TW;  // block tile edge
+  constexpr int LDT = ldt<TB>();
+  constexpr int NV = MBK * TB / 1024;
   A.p += (int64_t)blockIdx.y * bt.sa;
   B.p += (int64_t)blockIdx.y * bt.sb;
   C += (int64_t)blockIdx.y * bt.sc;
@@ -264,16 +297,16 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int tm, tn;
   tile_of_block(tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int m0 = tm * TB, n0 = tn * TB;
+  const int wm = (w >> 1) * 32 * TW, wn = (w & 1) * 32 * TW;
   const int li = lane & 31, lk = lane >> 5;
   const int K = A.K;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TW][TW];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < TW; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < TW; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         acc[i][j][r] = 0.f;
@@ -284,48 +317,57 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
         }
       }
 
-  f32x4 pa[MBK / 8], pb[MBK / 8];
-  tile_load<A_KCONT, FULL, MBK>(A, m0, 0, tid, pa);
-  tile_load<B_KCONT, FULL, MBK>(B, n0, 0, tid, pb);
-  tile_store<A_KCONT, MBK>(As[0], tid, pa);
-  tile_store<B_KCONT, MBK>(Bs[0], tid, pb);
+  f32x4 pa[NV], pb[NV];
+  const float *abase = A.p, *bbase = B.p;
+  tile_load<A_KCONT, FULL, MBK, TB>(A, abase, m0, 0, tid, pa);
+  tile_load<B_KCONT, FULL, MBK, TB>(B, bbase, n0, 0, tid, pb);
+  tile_store<A_KCONT, MBK, TB>(As[0], tid, pa);
+  tile_store<B_KCONT, MBK, TB>(Bs[0], tid, pb);
   __syncthreads();
 
   int cur = 0;
-  for (int k0 = 0; k0 < K; k0 += MBK) {
-    const bool more = k0 + MBK < K;
+  const int kt = (K + MBK - 1) / MBK, total = kt * bt.nseg;
+  int nk0 = 0;  // k offset of the tile being prefetched
+  for (int it = 0; it < total; it++) {
+    const bool more = it + 1 < total;
     if (more) {
-      tile_load<A_KCONT, FULL, MBK>(A, m0, k0 + MBK, tid, pa);
-      tile_load<B_KCONT, FULL, MBK>(B, n0, k0 + MBK, tid, pb);
+      nk0 += MBK;
+      if (nk0 >= K) {  // next k segment
+        nk0 = 0;
+        abase += bt.ka;
+        bbase += bt.kb;
+      }
+      tile_load<A_KCONT, FULL, MBK, TB>(A, abase, m0, nk0, tid, pa);
+      tile_load<B_KCONT, FULL, MBK, TB>(B, bbase, n0, nk0, tid, pb);
     }
     const float *as = As[cur] + lk * LDT + wm + li, *bs = Bs[cur] + lk * LDT + wn + li;
     // operand fragments one k-pair ahead of the MFMAs that consume them (register double buffer), so the
-    // LDS latency of step s+1 runs under the four MFMAs of step s
-    float a[2][2], b[2][2];
+    // LDS latency of step s+1 runs under the MFMAs of step s
+    float a[2][TW], b[2][TW];
 #pragma unroll
-    for (int i = 0; i < 2; i++) a[0][i] = as[i * 32];
+    for (int i = 0; i < TW; i++) a[0][i] = as[i * 32];
 #pragma unroll
-    for (int j = 0; j < 2; j++) b[0][j] = bs[j * 32];
+    for (int j = 0; j < TW; j++) b[0][j] = bs[j * 32];
 #pragma unroll
     for (int st = 0; st < MBK / 2; st++) {
       const int c = st & 1;
       if (st + 1 < MBK / 2) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) a[c ^ 1][i] = as[(st + 1) * 2 * LDT + i * 32];
+        for (int i = 0; i < TW; i++) a[c ^ 1][i] = as[(st + 1) * 2 * LDT + i * 32];
 #pragma unroll
-        for (int j = 0; j < 2; j++) b[c ^ 1][j] = bs[(st + 1) * 2 * LDT + j * 32];
+        for (int j = 0; j < TW; j++) b[c ^ 1][j] = bs[(st + 1) * 2 * LDT + j * 32];
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the reads of step st+1 ahead of the MFMAs of step st
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int i = 0; i < TW; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TW; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
-      tile_store<A_KCONT, MBK>(As[cur ^ 1], tid, pa);
-      tile_store<B_KCONT, MBK>(Bs[cur ^ 1], tid, pb);
+      tile_store<A_KCONT, MBK, TB>(As[cur ^ 1], tid, pa);
+      tile_store<B_KCONT, MBK, TB>(Bs[cur ^ 1], tid, pb);
     }
     __syncthreads();
     cur ^= 1;
@@ -334,9 +376,9 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
   const int M = A.R, N = B.R;
   if constexpr (CHAIN) {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TW; i++)
 #pragma unroll
-      for (int j = 0; j < 2; j++)
+      for (int j = 0; j < TW; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -344,12 +386,12 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
           if (FULL || (row < M && col < N)) C[(int64_t)row * ldc + col] = acc[i][j][r];
         }
   } else {
-    // per 32x32 MFMA tile: its 16 reads of C first (independent), then the 16 read-modify-writes -- four
-    // memory round trips per lane instead of 64, without holding all of C in registers
+    // per 32x32 MFMA tile: its 16 reads of C first (independent), then the 16 read-modify-writes -- one
+    // memory round trip per tile instead of 16, without holding all of C in registers
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TW; i++)
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
+      for (int j = 0; j < TW; j++) {
         f32x16 cin;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -377,9 +419,13 @@ template <bool CHAIN, bool FULL> seqk_fn pick_seqk(bool a_kcont, bool b_kcont) {
   return a_kcont ? (b_kcont ? gemm_seqk_kernel<true, true, CHAIN, FULL> : gemm_seqk_kernel<true, false, CHAIN, FULL>)
                  : (b_kcont ? gemm_seqk_kernel<false, true, CHAIN, FULL> : gemm_seqk_kernel<false, false, CHAIN, FULL>);
 }
-template <bool CHAIN, bool FULL> mfma_fn pick_mfma(bool a_kcont, bool b_kcont) {
-  return a_kcont ? (b_kcont ? gemm_mfma_kernel<true, true, CHAIN, FULL> : gemm_mfma_kernel<true, false, CHAIN, FULL>)
-                 : (b_kcont ? gemm_mfma_kernel<false, true, CHAIN, FULL> : gemm_mfma_kernel<false, false, CHAIN, FULL>);
+template <bool CHAIN, bool FULL, int TW> mfma_fn pick_mfma(bool a_kcont, bool b_kcont) {
+  return a_kcont ? (b_kcont ? gemm_mfma_kernel<true, true, CHAIN, FULL, TW> : gemm_mfma_kernel<true, false, CHAIN, FULL, TW>)
+                 : (b_kcont ? gemm_mfma_kernel<false, true, CHAIN, FULL, TW> : gemm_mfma_kernel<false, false, CHAIN, FULL, TW>);
+}
+template <int TW> mfma_fn pick_mfma_tw(bool chain, bool full, bool a_kcont, bool b_kcont) {
+  return chain ? (full ? pick_mfma<true, true, TW>(a_kcont, b_kcont) : pick_mfma<true, false, TW>(a_kcont, b_kcont))
+               : (full ? pick_mfma<false, true, TW>(a_kcont, b_kcont) : pick_mfma<false, false, TW>(a_kcont, b_kcont));
 }
 
 int launch_gemm(const char *who, float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
@@ -406,12 +452,18 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   a.vec = aligned16(A) && (lda % 4 == 0) && (bt.sa % 4 == 0) && ((a_kcont ? K : M) % 4 == 0);
   b.vec = aligned16(B) && (ldb % 4 == 0) && (bt.sb % 4 == 0) && ((b_kcont ? K : N) % 4 == 0);
   const int c_vec = aligned16(C) && (ldc % 4 == 0) && (bt.sc % 4 == 0) && (N % 4 == 0);
-  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+  if (bt.nseg < 1) return fail(FPEMU_EINVAL, "k_segments must be >= 1");
+  if (bt.nseg > 1 && ((bt.ka % 4) || (bt.kb % 4))) a.vec = b.vec = 0;
+  // Tile edge: 128 unless that leaves the chip mostly idle (fewer tiles than two per CU) -- a chain cannot
+  // be split along k, so small M x N problems get 64 x 64 tiles (MFMA kernel only).
+  const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch;
+  const int tb = (variant == 1 && t128 < 512) ? 64 : 128;
+  const int tiles_m = (int)((M + tb - 1) / tb), tiles_n = (int)((N + tb - 1) / tb);
   const int64_t nwg = (int64_t)tiles_m * tiles_n;
   if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "too many tiles");
   const float beta = 0.0f;  // simple_gemm.cpp:58
   // every tile whole and 16-byte loads everywhere: the kernels drop their bounds tests
-  const bool full = a.vec && b.vec && (M % BM == 0) && (N % BN == 0) && (K % (variant == 1 ? MBK : BK) == 0) && K > 0;
+  const bool full = a.vec && b.vec && (M % tb == 0) && (N % tb == 0) && (K % (variant == 1 ? MBK : BK) == 0) && K > 0;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)nwg, (unsigned)batch);
   if (variant == 0) {
@@ -419,8 +471,7 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
                        : (full ? pick_seqk<false, true>(a_kcont, b_kcont) : pick_seqk<false, false>(a_kcont, b_kcont));
     hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, c_vec, alpha, beta, tiles_m, tiles_n, bt);
   } else if (variant == 1) {
-    mfma_fn fn = chain ? (full ? pick_mfma<true, true>(a_kcont, b_kcont) : pick_mfma<true, false>(a_kcont, b_kcont))
-                       : (full ? pick_mfma<false, true>(a_kcont, b_kcont) : pick_mfma<false, false>(a_kcont, b_kcont));
+    mfma_fn fn = tb == 64 ? pick_mfma_tw<1>(chain, full, a_kcont, b_kcont) : pick_mfma_tw<2>(chain, full, a_kcont, b_kcont);
     hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);
   } else {
     return fail(FPEMU_EINVAL, "unknown variant");
@@ -435,13 +486,19 @@ extern "C" int fpemu_gemm_f32(float *C, const float *A, const float *B, int64_t 
                               int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans,
                               int b_trans, int variant, void *stream) {
   return launch_gemm("fpemu_gemm_f32", C, A, B, M, N, K, lda, ldb, ldc, alpha, a_trans, b_trans, variant, false,
-                     1, Batch{0, 0, 0}, stream);
+                     1, Batch{0, 0, 0, 0, 0, 1}, stream);
 }
 
 extern "C" int fpemu_gemm_chain_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
                                     int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans,
                                     int variant, int64_t batch, int64_t stride_a, int64_t stride_b,
-                                    int64_t stride_c, void *stream) {
+                                    int64_t stride_c, int64_t k_segments, int64_t kseg_stride_a,
+                                    int64_t kseg_stride_b, void *stream) {
+  if (k_segments < 1 || k_segments > 0x7FFFFFFF) {
+    fpemu_set_error_("fpemu_gemm_chain_f32: k_segments out of range");
+    return FPEMU_EINVAL;
+  }
   return launch_gemm("fpemu_gemm_chain_f32", C, A, B, M, N, K, lda, ldb, ldc, 1.0f, a_trans, b_trans, variant,
-                     true, batch, Batch{stride_a, stride_b, stride_c}, stream);
+                     true, batch, Batch{stride_a, stride_b, stride_c, kseg_stride_a, kseg_stride_b, (int)k_segments},
+                     stream);
 }

@@ -64,7 +64,7 @@ def lib():
         L.fpemu_gemm_f32.restype = i32
         L.fpemu_gemm_f32.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, i32, i32, i32, vp]
         L.fpemu_gemm_chain_f32.restype = i32
-        L.fpemu_gemm_chain_f32.argtypes = [vp, vp, vp] + [i64] * 6 + [i32, i32, i32] + [i64] * 4 + [vp]
+        L.fpemu_gemm_chain_f32.argtypes = [vp, vp, vp] + [i64] * 6 + [i32, i32, i32] + [i64] * 7 + [vp]
         L.fpemu_conv2d_workspace_bytes.restype = u64
         L.fpemu_conv2d_workspace_bytes.argtypes = [i32] + [i64] * 9
         L.fpemu_conv2d_fp_f32.restype = i32
@@ -77,7 +77,7 @@ def lib():
         L.fpemu_set_max_blocks.argtypes = [i32]
         L.fpemu_quantize_blocks.restype = i32
         L.fpemu_quantize_blocks.argtypes = [vp, vp, u64, u64, i32, i32, i32, u64, u64, vp]
-        if L.fpemu_abi_version() != 2:
+        if L.fpemu_abi_version() != 3:
             raise ImportError("libfpemu_hip.so: ABI version mismatch")
         _lib = L
     return _lib

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FPEMU_ABI_VERSION 2
+#define FPEMU_ABI_VERSION 3
 
 /* Storage dtype of in/out buffers. */
 enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
@@ -172,10 +172,14 @@ int fpemu_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t 
  * accumulators START at C's current values and C = acc (what MMEngine_avx2_ps does inside the
  * reference's conv kernels: load C, continue the k-ascending chain, store; simple_mm_engine.cpp:18-24),
  * instead of simple_gemm's C += alpha*acc.  `batch` independent problems; operand b is at
- * X + b*stride_x elements (stride 0 = shared).  variant as fpemu_gemm_f32. */
+ * X + b*stride_x elements (stride 0 = shared).  k_segments >= 1: the k loop runs that many times over
+ * K into the same accumulators, A and B advancing by kseg_stride_a / _b elements each time -- ONE chain
+ * of k_segments*K products (the conv weight update chains image after image,
+ * simple_conv2d_impl.cpp:645-667).  variant as fpemu_gemm_f32. */
 int fpemu_gemm_chain_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
                          int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans, int variant,
-                         int64_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, void *stream);
+                         int64_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                         int64_t k_segments, int64_t kseg_stride_a, int64_t kseg_stride_b, void *stream);
 
 /* cmodel direct convolution: replaces simple_conv2d_dev.conv2d_fp / conv2d_bp / conv2d_wu
  * (mpemu/cmodel/simple/simple_conv2d.cpp:44-121 -> simple_conv2d_impl.cpp:677-977).  NCHW activations,

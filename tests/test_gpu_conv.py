@@ -55,7 +55,8 @@ def test_conv_vs_reference_fixture(hip, bname, variant, fused):
 @pytest.mark.parametrize("bname,variant,fused", VARIANTS)
 @pytest.mark.parametrize("case", [(2, 3, 32, 32, 64, 7, 7, 2, 3), (4, 64, 14, 14, 64, 3, 3, 1, 1),
                                   (3, 16, 9, 11, 24, 3, 3, 1, 1), (2, 128, 8, 8, 128, 1, 1, 2, 0),
-                                  (1, 64, 28, 28, 192, 3, 3, 2, 1), (5, 1, 5, 5, 1, 5, 5, 1, 0)])
+                                  (1, 64, 28, 28, 192, 3, 3, 2, 1), (5, 1, 5, 5, 1, 5, 5, 1, 0),
+                                  (40, 64, 28, 28, 256, 3, 3, 1, 1)])   # >= 512 tiles: the 128 x 128 kernels
 def test_conv_vs_oracle(hip, bname, variant, fused, case):
     """Batches with C or K < 64 included: every image is convolved (the reference collapses them)."""
     N, C, H, W, K, R, S, st, pd = case

@@ -44,7 +44,8 @@ def test_gemm_vs_reference_fixture(hip, bname, variant, fused):
 
 @pytest.mark.parametrize("bname,variant,fused", VARIANTS)
 @pytest.mark.parametrize("shape", [(1, 1, 1), (7, 5, 3), (128, 128, 16), (129, 127, 17), (256, 384, 512),
-                                   (300, 200, 1000), (64, 1024, 33), (1000, 8, 2048)])
+                                   (300, 200, 1000), (64, 1024, 33), (1000, 8, 2048),
+                                   (2950, 2944, 70), (2944, 2944, 64)])   # >= 512 tiles: the 128 x 128 kernels
 @pytest.mark.parametrize("at,bt", [(False, False), (True, False), (False, True), (True, True)])
 def test_gemm_vs_oracle(hip, bname, variant, fused, shape, at, bt):
     M, N, K = shape
@@ -121,3 +122,37 @@ def test_simple_module_api(hip):
         simple.set_accumulation("fma")
     with pytest.warns(UserWarning):
         simple.mm(_t(a).double(), _t(b).double())
+
+
+@pytest.mark.parametrize("variant,fused", [(1, True), (0, False)])
+def test_gemm_chain_k_segments_and_batch(hip, variant, fused):
+    """fpemu_gemm_chain_f32: accumulators start at C; k segments chain several (A, B) pairs into one chain;
+    batch = independent problems.  Oracle: the same chain as one long-K GEMM started from C."""
+    import ctypes
+
+    rng = np.random.default_rng(4)
+    nb, nseg, M, N, K = 3, 4, 70, 90, 50
+    A = rng.standard_normal((nb, nseg, M, K)).astype(np.float32)
+    B = rng.standard_normal((nb, nseg, K, N)).astype(np.float32)
+    C0 = rng.standard_normal((nb, M, N)).astype(np.float32)
+    tA, tB, tC = _t(A), _t(B), _t(C0)
+    L = hip.lib()
+    rc = L.fpemu_gemm_chain_f32(tC.data_ptr(), tA.data_ptr(), tB.data_ptr(), M, N, K, K, N, N, 0, 0, variant,
+                                nb, nseg * M * K, nseg * K * N, M * N, nseg, M * K, K * N, None)
+    assert rc == 0, L.fpemu_last_error()
+    torch.cuda.synchronize()
+    for b in range(nb):
+        # chain from C0: out = C0 then fmaf / mul+add over the concatenated k -- the oracle's GEMM chain with
+        # alpha = 1 starts at +0, so restate the chain directly
+        want = C0[b].copy()
+        Acat = np.concatenate([A[b, sgm] for sgm in range(nseg)], axis=1)
+        Bcat = np.concatenate([B[b, sgm] for sgm in range(nseg)], axis=0)
+        for k in range(Acat.shape[1]):
+            a, bb = Acat[:, k:k + 1], Bcat[k:k + 1, :]
+            if fused:
+                want = (a.astype(np.float64) * bb.astype(np.float64) + want.astype(np.float64)).astype(np.float32)
+            else:
+                want = want + (a * bb)
+        assert_bits_equal(tC[b].cpu().numpy(), want, "chain batch %d" % b)
+    assert L.fpemu_gemm_chain_f32(tC.data_ptr(), tA.data_ptr(), tB.data_ptr(), M, N, K, K, N, N, 0, 0, variant,
+                                  1, 0, 0, 0, 0, 0, 0, None) == -1   # k_segments < 1
