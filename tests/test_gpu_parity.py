@@ -101,6 +101,18 @@ def test_full_size_config1_e4m3(hip):
     assert_bits_equal(gpu_cast(hip, x, "E4M3_RNE"), orc.cast(x, "E4M3_RNE"), "config1")
 
 
+def test_full_size_config1_e4m3_per_tensor_max(hip):
+    """BASELINE config 1, second half: the same tensor with the per-tensor max scale derived on device."""
+    torch.manual_seed(0)
+    x = torch.randn(4096, 4096)
+    fmt, rm = hip.parse_mode("E4M3_RNE")
+    t = x.to(DEV)
+    o = torch.empty_like(t)
+    hip.quantize_per_tensor_(t, o, fmt, rm, 448.0)
+    s = orc.scale_from_amax(orc.amax(x.numpy()), 448.0)
+    assert_bits_equal(o.cpu().numpy(), orc.cast(x.numpy(), "E4M3_RNE", scale=s), "config1 per-tensor max")
+
+
 @pytest.mark.parametrize("mode", ALL_MODES)
 def test_16mi_prefix_all_modes_vs_oracle(hip, mode):
     """BASELINE config 2 input mix, 16 Mi elements, every format x rounding mode."""
