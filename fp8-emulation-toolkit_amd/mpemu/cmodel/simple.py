@@ -43,6 +43,8 @@ def get_accumulation():
 
 
 def is_transposed(input):
+    """(matrix to hand to the GEMM, transposed flag): a transposed view of a contiguous matrix is passed as
+    a flag, anything else is made contiguous (reference simple.py:21-27)."""
     if input.is_contiguous():
         return input, False
     if input.t().is_contiguous():
@@ -50,57 +52,61 @@ def is_transposed(input):
     return input.contiguous(), False
 
 
-def _out_shape(a_mat, a_trans, b_mat, b_trans):
-    return [a_mat.size(1) if a_trans else a_mat.size(0), b_mat.size(0) if b_trans else b_mat.size(1)]
-
-
 def _gemm(out, a, b, alpha, a_trans, b_trans):
     return _hip.gemm_(out, a, b, alpha, a_trans, b_trans, _variant)
 
 
-def _supported(*ts):
+def _on_gpu_f32(*ts):
     return all(t.dtype == torch.float32 and t.is_cuda for t in ts)
 
 
+def _mat2(a, b):
+    """Both 2-D with matching inner dimension."""
+    return a.dim() == 2 and b.dim() == 2 and a.size(1) == b.size(0)
+
+
+def _fresh(m, n, like):
+    return torch.zeros([m, n], device=like.device)
+
+
+def _decline(op, fallback, shapes, *args, **kwargs):
+    warnings.warn("simple.%s: unsupported operands %s -- using torch.%s" % (op, shapes, op))
+    return fallback(*args, **kwargs)
+
+
 def addmm(input, mat1, mat2, beta=1.0, alpha=1.0, out=None):
-    if _supported(input, mat1, mat2) and mat1.dim() == 2 and mat2.dim() == 2 and mat1.size(1) == mat2.size(0):
-        a_mat, a_trans = is_transposed(mat1)
-        b_mat, b_trans = is_transposed(mat2)
-        output = out if out is not None else torch.zeros(_out_shape(a_mat, a_trans, b_mat, b_trans),
-                                                         device=mat1.device)
-        return SimpleAddmm.apply(output, input, a_mat, b_mat, alpha, beta, a_trans, b_trans)
-    warnings.warn('simple.addmm does not support the input dimensions - input :{}, mat1: {}, mat2: {}, '
-                  'falling back to torch.addmm'.format(input.size(), mat1.size(), mat2.size()))
-    return fallback_addmm(input, mat1, mat2, beta=beta, alpha=alpha, out=out)
+    if not (_on_gpu_f32(input, mat1, mat2) and _mat2(mat1, mat2)):
+        return _decline("addmm", fallback_addmm, (tuple(input.size()), tuple(mat1.size()), tuple(mat2.size())),
+                        input, mat1, mat2, beta=beta, alpha=alpha, out=out)
+    a_mat, a_trans = is_transposed(mat1)
+    b_mat, b_trans = is_transposed(mat2)
+    output = out if out is not None else _fresh(mat1.size(0), mat2.size(1), mat1)
+    return SimpleAddmm.apply(output, input, a_mat, b_mat, alpha, beta, a_trans, b_trans)
+
+
+def mm(input, mat2, out=None):
+    if not (_on_gpu_f32(input, mat2) and _mat2(input, mat2)):
+        return _decline("mm", fallback_mm, (tuple(input.size()), tuple(mat2.size())), input, mat2, out=out)
+    a_mat, a_trans = is_transposed(input)
+    b_mat, b_trans = is_transposed(mat2)
+    output = out if out is not None else _fresh(input.size(0), mat2.size(1), input)
+    return SimpleMatmul.apply(output, a_mat, b_mat, 1.0, a_trans, b_trans)
 
 
 def matmul(input, other, out=None):
-    if _supported(input, other) and input.dim() == 2 and other.dim() == 2 and input.size(1) == other.size(0):
+    if _on_gpu_f32(input, other) and _mat2(input, other):
         return mm(input, other, out=out)
-    if _supported(input, other) and input.dim() == 3 and other.dim() == 2 and input.size(2) == other.size(0):
+    if _on_gpu_f32(input, other) and input.dim() == 3 and other.dim() == 2 and input.size(2) == other.size(0):
+        # a stack of matrices times one matrix: one c-model GEMM per slice (reference simple.py:52-63)
         b_mat, b_trans = is_transposed(other)
-        n = b_mat.size(0) if b_trans else b_mat.size(1)
-        outs = out if out is not None else torch.zeros([input.size(0), input.size(1), n], device=input.device)
+        outs = out if out is not None else torch.zeros([input.size(0), input.size(1), other.size(1)],
+                                                       device=input.device)
         res = []
         for i in range(input.size(0)):
             a_mat, a_trans = is_transposed(input[i])
             res.append(SimpleMatmul.apply(outs[i], a_mat, b_mat, 1.0, a_trans, b_trans))
         return torch.stack(res)
-    warnings.warn('simple.matmul does not support the input dimensions - input :{}, other: {}, falling back '
-                  'to torch.matmul'.format(input.size(), other.size()))
-    return fallback_matmul(input, other, out=out)
-
-
-def mm(input, mat2, out=None):
-    if _supported(input, mat2) and input.dim() == 2 and mat2.dim() == 2 and input.size(1) == mat2.size(0):
-        a_mat, a_trans = is_transposed(input)
-        b_mat, b_trans = is_transposed(mat2)
-        output = out if out is not None else torch.zeros(_out_shape(a_mat, a_trans, b_mat, b_trans),
-                                                         device=input.device)
-        return SimpleMatmul.apply(output, a_mat, b_mat, 1.0, a_trans, b_trans)
-    warnings.warn('simple.mm does not support the input dimensions - input :{}, mat2: {}, falling back to '
-                  'torch.mm'.format(input.size(), mat2.size()))
-    return fallback_mm(input, mat2, out=out)
+    return _decline("matmul", fallback_matmul, (tuple(input.size()), tuple(other.size())), input, other, out=out)
 
 
 def _pair(v):
