@@ -87,46 +87,60 @@ __global__ __launch_bounds__(NT) void pack_w_bp(const float *__restrict__ w, flo
   }
 }
 
-// cols[n][(cb, kj, ki, c2)][(oj, oi)] = x[n0 + n][cb*CB + c2][oj*s + kj - pad][oi*s + ki - pad], 0 outside
+// cols[n][(cb, kj, ki, c2)][(oj, oi)] = x[n0 + n][cb*CB + c2][oj*s + kj - pad][oi*s + ki - pad], 0 outside.
+// One (image, kk) row of the gathered matrix per blockIdx.y (decoded once, scalar), threads along the
+// pixels: coalesced stores, row-local loads, 32-bit index arithmetic per element.
 __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float *__restrict__ cols, Geo g,
-                                              int64_t nimg) {
-  const int64_t P = g.OH * g.OW, crs = g.C * g.R * g.S, total = nimg * crs * P;
-  for (int64_t i = gtid(); i < total; i += gstride()) {
-    const int64_t p = i % P;
-    int64_t kk = (i / P) % crs;
-    const int64_t n = i / (P * crs);
-    const int64_t c2 = kk % g.CB; kk /= g.CB;
-    const int64_t ki = kk % g.S; kk /= g.S;
-    const int64_t kj = kk % g.R;
-    const int64_t cb = kk / g.R;
-    const int64_t oj = p / g.OW, oi = p % g.OW;
-    const int64_t y = oj * g.stride + kj - g.pad, xx = oi * g.stride + ki - g.pad;
-    float v = 0.f;
-    if (y >= 0 && y < g.H && xx >= 0 && xx < g.W) v = x[((n * g.C + cb * g.CB + c2) * g.H + y) * g.W + xx];
-    cols[i] = v;
+                                              int64_t nrows) {
+  const int P = (int)(g.OH * g.OW), OW = (int)g.OW, H = (int)g.H, W = (int)g.W, st = (int)g.stride;
+  const int crs = (int)(g.C * g.R * g.S);
+  for (int64_t row = blockIdx.y; row < nrows; row += gridDim.y) {
+    int kk = (int)(row % crs);
+    const int64_t n = row / crs;
+    const int c2 = kk % (int)g.CB; kk /= (int)g.CB;
+    const int ki = kk % (int)g.S; kk /= (int)g.S;
+    const int kj = kk % (int)g.R;
+    const int cb = kk / (int)g.R;
+    const float *src = x + (n * g.C + cb * g.CB + c2) * (int64_t)H * W;
+    float *dst = cols + row * P;
+    const int y0 = kj - (int)g.pad, x0 = ki - (int)g.pad;
+    for (int p = blockIdx.x * NT + threadIdx.x; p < P; p += gridDim.x * NT) {
+      const int oj = p / OW, oi = p - oj * OW;
+      const int y = oj * st + y0, xx = oi * st + x0;
+      float v = 0.f;
+      if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = src[y * W + xx];
+      dst[p] = v;
+    }
   }
 }
 
 // colsb[n][(ob, tj, ti, o2)][(ih, iw)] = gout[n][ob*KB + o2][oj][oi] with kj = R-1-tj, ki = ti,
-// oj = (ih + pad - kj)/s, oi = (iw + pad - ki)/s when those divide and are in range, else 0
+// oj = (ih + pad - kj)/s, oi = (iw + pad - ki)/s when those divide and are in range, else 0.
+// Same decomposition: one gathered row per blockIdx.y, threads along the input pixels.
 __global__ __launch_bounds__(NT) void cols_bp(const float *__restrict__ go, float *__restrict__ cols, Geo g,
-                                              int64_t nimg) {
-  const int64_t HW = g.H * g.W, krs = g.K * g.R * g.S, total = nimg * krs * HW, P = g.OH * g.OW;
-  for (int64_t i = gtid(); i < total; i += gstride()) {
-    const int64_t pix = i % HW;
-    int64_t kk = (i / HW) % krs;
-    const int64_t n = i / (HW * krs);
-    const int64_t o2 = kk % g.KB; kk /= g.KB;
-    const int64_t ti = kk % g.S; kk /= g.S;
-    const int64_t tj = kk % g.R;
-    const int64_t ob = kk / g.R;
-    const int64_t dy = pix / g.W + g.pad - (g.R - 1 - tj), dx = pix % g.W + g.pad - ti;
-    float v = 0.f;
-    if (dy >= 0 && dx >= 0 && dy % g.stride == 0 && dx % g.stride == 0) {
-      const int64_t oj = dy / g.stride, oi = dx / g.stride;
-      if (oj < g.OH && oi < g.OW) v = go[(n * g.K + ob * g.KB + o2) * P + oj * g.OW + oi];
+                                              int64_t nrows) {
+  const int HW = (int)(g.H * g.W), W = (int)g.W, OH = (int)g.OH, OW = (int)g.OW, st = (int)g.stride;
+  const int krs = (int)(g.K * g.R * g.S);
+  for (int64_t row = blockIdx.y; row < nrows; row += gridDim.y) {
+    int kk = (int)(row % krs);
+    const int64_t n = row / krs;
+    const int o2 = kk % (int)g.KB; kk /= (int)g.KB;
+    const int ti = kk % (int)g.S; kk /= (int)g.S;
+    const int tj = kk % (int)g.R;
+    const int ob = kk / (int)g.R;
+    const float *src = go + (n * g.K + ob * g.KB + o2) * (int64_t)OH * OW;
+    float *dst = cols + row * HW;
+    const int y0 = (int)g.pad - ((int)g.R - 1 - tj), x0 = (int)g.pad - ti;
+    for (int pix = blockIdx.x * NT + threadIdx.x; pix < HW; pix += gridDim.x * NT) {
+      const int ih = pix / W, iw = pix - ih * W;
+      const int dy = ih + y0, dx = iw + x0;
+      float v = 0.f;
+      if (dy >= 0 && dx >= 0) {
+        const int oj = dy / st, oi = dx / st;
+        if (oj * st == dy && oi * st == dx && oj < OH && oi < OW) v = src[oj * OW + oi];
+      }
+      dst[pix] = v;
     }
-    cols[i] = v;
   }
 }
 
@@ -141,6 +155,17 @@ __global__ __launch_bounds__(NT) void fill_rows(float *__restrict__ out, const f
     }
     out[i] = b;
   }
+}
+
+// grid for the gather kernels: x over the pixels of a row, y over (image, kk) rows
+dim3 gather_grid(int64_t pixels, int64_t nrows) {
+  // one block walks a whole row (its decode is amortised over the row) unless rows are very long
+  int64_t gx = (pixels + 16 * NT - 1) / (16 * NT);
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  int64_t gy = nrows < 65535 ? nrows : 65535;
+  if (gy < 1) gy = 1;
+  return dim3((unsigned)gx, (unsigned)gy);
 }
 
 unsigned blocks_for(int64_t total) {
@@ -241,7 +266,7 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   CHECK_LAUNCH(who);
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL(cols_fp, dim3(blocks_for(nb * crs * P)), dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb);
+    hipLaunchKernelGGL(cols_fp, gather_grid(P, nb * crs), dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_f32(out + n0 * K * P, Wm, cols, K, P, crs, crs, P, P, 0, 0, variant, nb, 0, crs * P,
                               K * P, 1, 0, 0, stream);
@@ -273,7 +298,7 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
   CHECK_LAUNCH(who);
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL(cols_bp, dim3(blocks_for(nb * krs * HW)), dim3(NT), 0, s, gout + n0 * K * P, cols, g, nb);
+    hipLaunchKernelGGL(cols_bp, gather_grid(HW, nb * krs), dim3(NT), 0, s, gout + n0 * K * P, cols, g, nb * krs);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_f32(gin + n0 * C * HW, Wm, cols, C, HW, krs, krs, HW, HW, 0, 0, variant, nb, 0, krs * HW,
                               C * HW, 1, 0, 0, stream);
@@ -303,7 +328,7 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
   CHECK_LAUNCH(who);
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL(cols_fp, dim3(blocks_for(nb * crs * P)), dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb);
+    hipLaunchKernelGGL(cols_fp, gather_grid(P, nb * crs), dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs);
     CHECK_LAUNCH(who);
     // one chain across the chunk's images in ONE launch: k segments = images (chunks follow in order)
     rc = fpemu_gemm_chain_f32(Gm, gout + n0 * K * P, cols, K, crs, P, P, P, crs, 0, 1, variant, 1, 0, 0, 0, nb,

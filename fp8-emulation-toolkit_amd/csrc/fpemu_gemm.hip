@@ -457,7 +457,7 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   // Tile edge: 128 unless that leaves the chip mostly idle (fewer tiles than two per CU) -- a chain cannot
   // be split along k, so small M x N problems get 64 x 64 tiles (MFMA kernel only).
   const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch;
-  const int tb = (variant == 1 && t128 < 512) ? 64 : 128;
+  const int tb = (variant == 1 && (t128 < 512 || M <= 64 || N <= 64)) ? 64 : 128;
   const int tiles_m = (int)((M + tb - 1) / tb), tiles_n = (int)((N + tb - 1) / tb);
   const int64_t nwg = (int64_t)tiles_m * tiles_n;
   if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "too many tiles");

@@ -23,7 +23,8 @@ def timed(fn, iters=3):
     return e0.elapsed_time(e1) / iters
 
 
-for (N, C, H, W, K, R, S, st, pd) in LAYERS:
+sel = [int(a) for a in sys.argv[1:]]
+for (N, C, H, W, K, R, S, st, pd) in ([LAYERS[i] for i in sel] if sel else LAYERS):
     OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
     x = torch.randn(N, C, H, W, device="cuda")
     w = torch.randn(K, C, R, S, device="cuda")
