@@ -1,0 +1,59 @@
+"""The entry points only enqueue work on the caller's stream (no allocation, no sync), so a sequence of
+them can be captured into a HIP graph and replayed on new data: launch-bound per-layer casts become one
+graph launch."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from _util import assert_bits_equal, mixed_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_cast_quantize_gemm_under_graph_capture():
+    from mpemu.pytquant.hip import _binding as hip
+
+    hip.lib()
+    n = 70001
+    x = torch.zeros(n, device=DEV)
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    ws = torch.zeros(1, dtype=torch.int32, device=DEV)
+    a = torch.zeros(96, 80, device=DEV)
+    b = torch.zeros(80, 72, device=DEV)
+    c = torch.zeros(96, 72, device=DEV)
+    f4, r4 = hip.parse_mode("E4M3_RNE")
+    f5, r5 = hip.parse_mode("E5M2_STOCHASTIC")
+
+    def work():
+        hip.cast_(x, y, f5, r5, scale=1.0, seed=3, offset=7)
+        hip.quantize_per_tensor_(x, z, f4, r4, 448.0, amax_ws=ws)
+        c.zero_()
+        hip.gemm_(c, a, b, 1.0, False, False, hip.GEMM_FMA)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        work()                       # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        work()
+    for seed in (1, 2):
+        hx = mixed_inputs(n, seed=seed)
+        hx[np.isnan(hx)] = 0.25
+        rng = np.random.default_rng(seed)
+        ha = rng.standard_normal((96, 80)).astype(np.float32)
+        hb = rng.standard_normal((80, 72)).astype(np.float32)
+        x.copy_(torch.from_numpy(hx))
+        a.copy_(torch.from_numpy(ha))
+        b.copy_(torch.from_numpy(hb))
+        g.replay()
+        torch.cuda.synchronize()
+        assert_bits_equal(y.cpu().numpy(), orc.cast(hx, "E5M2_STOCHASTIC", seed=3, offset=7), "graph cast")
+        sc = orc.scale_from_amax(orc.amax(hx), 448.0)
+        assert_bits_equal(z.cpu().numpy(), orc.cast(hx, "E4M3_RNE", scale=sc), "graph per-tensor quantise",
+                          nan_payload_ok=True)
+        assert_bits_equal(c.cpu().numpy(), orc.gemm(ha, hb, fused=True), "graph gemm")
