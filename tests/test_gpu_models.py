@@ -201,3 +201,39 @@ def test_bert_base_ptq_e4m3():
     with torch.no_grad():
         out = model(input_ids=ids).last_hidden_state
     assert out.shape == (2, 128, 768) and torch.isfinite(out).all()
+
+
+def test_resnet50_hybrid_training_step():
+    """BASELINE config 4 at the real model's shape: ResNet-50 (random init, batch 8 of 3x64x64), one
+    mixed-precision training step through mpt_emu.initialize(training_algo="hybrid"): E4M3 per-tensor
+    weights / activations forward, E5M2 stochastic gradients, fp16 stochastic master weights."""
+    from _resnet import ResNet50
+
+    from mpemu import mpt_emu
+    from mpemu.pytquant.hip import fpemu as F
+
+    F.manual_seed(11)
+    torch.manual_seed(0)
+    model = ResNet50(classes=100).to(DEV).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    model, emu = mpt_emu.initialize(model, opt, training_algo="hybrid", device="cuda")
+    d = emu.emulator.model_qconfig_dict
+    convs = [n for n, m in model.named_modules() if isinstance(m, torch.nn.Conv2d)]
+    assert len(convs) == 53 and all(n in d for n in convs) and "fc" in d
+    x = torch.randn(8, 3, 64, 64, device=DEV)
+    target = torch.randint(0, 100, (8,), device=DEV)
+    w0 = model.layers[3].conv2.weight.detach().clone()
+    loss = torch.nn.functional.cross_entropy(model(x), target)
+    assert torch.isfinite(loss)
+    # the hooked conv weight now holds E4M3 values under its per-tensor max scale
+    wn = w0.cpu().numpy()
+    s = orc.scale_from_amax(orc.amax(wn), 448.0)
+    assert_bits_equal(model.layers[3].conv2.weight.detach().cpu().numpy(), orc.cast(wn, "E4M3_RNE", scale=s),
+                      "ResNet conv weight after the forward pre-hook")
+    loss.backward()
+    for name in ("layers.3.conv2", "layers.10.conv3", "fc"):
+        gw = dict(model.named_modules())[name].weight.grad
+        assert gw is not None and torch.isfinite(gw).all() and _is_fixed_point(gw, "E5M2_RTZ"), name
+    emu.optimizer_step(opt)
+    assert all(_is_fixed_point(p, "FLOAT16_RNE") for p in model.parameters())
+    assert not torch.equal(model.layers[3].conv2.weight.detach(), w0)
