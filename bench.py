@@ -180,6 +180,25 @@ def main():
             r_avg, _ = time_launches(rows_step, 10)
             extras["rows_16384x4096"] = {"ms": round(r_avg, 5), "GB/s": round(12 * xr.numel() / (r_avg * 1e-3) / 1e9, 1)}
 
+            # 16-bit storage (4 B/elem algorithmic) and block norm (12 B/elem: block max read + read + write)
+            xb = x[: 1 << 27].to(torch.bfloat16)
+            yb = torch.empty_like(xb)
+
+            def bf16_step():
+                hip.cast_(xb, yb, fmt, rm, scale=1.0)
+
+            bf16_step()
+            b_avg, _ = time_launches(bf16_step, 10)
+            extras["bf16_storage_128Mi"] = {"ms": round(b_avg, 5), "GB/s": round(4 * xb.numel() / (b_avg * 1e-3) / 1e9, 1)}
+            del xb, yb
+
+            def bn_step():
+                hip.quantize_blocks_(xr, yr, 64, fmt, rm)
+
+            bn_step()
+            n_avg, _ = time_launches(bn_step, 10)
+            extras["blocknorm_64_64Mi"] = {"ms": round(n_avg, 5), "GB/s": round(12 * xr.numel() / (n_avg * 1e-3) / 1e9, 1)}
+
             # cmodel emulated GEMM, BASELINE config 5's 8192^3: MFMA fmaf chain and VALU
             # separate-rounding chain, each against its own roofline (fp32 MFMA 157.3 / VALU mul+add 78.6)
             M = 8192

@@ -153,8 +153,11 @@ template <int DT> rows_fn pick_rows_dt(bool vec, int team, int fmt, int rm) {
 extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype,
                                   int fmt, int rmode, float flt_max, int policy, uint64_t seed,
                                   uint64_t offset, uint32_t *amax_out, int force_block, void *stream) {
-  const bool vec = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % vec_elems(dtype)) == 0;
   const int team = (force_block || rows == 1 || cols > kWaveRowCols) ? kBlock : cols > kLaneRowCols ? 64 : 1;
+  // 16-byte accesses only when every lane of the team gets at least one vector; shorter rows go one
+  // element per lane (still one coalesced segment per wave, and no idle lanes)
+  const bool vec = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % vec_elems(dtype)) == 0 &&
+                   cols >= (uint64_t)team * vec_elems(dtype);
   rows_fn fn = dtype == FPEMU_F32 ? pick_rows_dt<FPEMU_F32>(vec, team, fmt, rmode)
              : dtype == FPEMU_F16 ? pick_rows_dt<FPEMU_F16>(vec, team, fmt, rmode)
              : dtype == FPEMU_BF16 ? pick_rows_dt<FPEMU_BF16>(vec, team, fmt, rmode) : nullptr;
