@@ -44,6 +44,22 @@ template <int DT> __device__ __forceinline__ uint32_t store_elem16(float f) {
   else return f32_to_bf16_bits(f);
 }
 
+// Two fp32 results -> one dword of 16-bit storage (RNE).  Written as vector converts so that gfx950's
+// packed converts (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32) do the rounding: one instruction for the pair
+// instead of the integer RNE sequence per element.  (NaN payloads are the hardware's; every other value
+// is the same RNE.)
+template <int DT> __device__ __forceinline__ uint32_t pack_pair16(float y0, float y1) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t y = {y0, y1};
+  if constexpr (DT == FPEMU_F16) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(y, h2_t));
+  } else {
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(y, b2_t));
+  }
+}
+
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t m) {
 #pragma unroll

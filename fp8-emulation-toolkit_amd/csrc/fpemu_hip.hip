@@ -65,13 +65,16 @@ __device__ __forceinline__ uint32_t lane_noise(const Philox4 (&p)[NCALLS], unsig
   return w;  // consumers mask the bits they use
 }
 
-template <int RM> constexpr int slots_per_wave() { return RM == STOCHASTIC ? 4 : 1; }
+// 16-byte vectors per lane: 4 for stochastic modes (the noise layout's superblock); deterministic fp32
+// storage 1 (pure stream, measured fastest); deterministic 16-bit storage 2 (twice the ALU work per byte:
+// a second independent vector per lane hides it)
+template <int RM, int DT> constexpr int slots_per_wave() { return RM == STOCHASTIC ? 4 : (DT == FPEMU_F32 ? 1 : 2); }
 
 template <int FMT, int RM, int DT>
 __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out_,
                                                       uint64_t nsb, uint64_t n, CastParams prm) {
   constexpr unsigned V = Storage<DT>::V;
-  constexpr int U = slots_per_wave<RM>();
+  constexpr int U = slots_per_wave<RM, DT>();
   constexpr uint64_t SB_ELEMS = (uint64_t)V * 64u * U;
   constexpr bool SR = (RM == STOCHASTIC);
   constexpr int NCALLS = SR ? (int)(4u * V * noise_bytes<FMT>() / 16u) : 1;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out
           const uint32_t r1 = SR ? lane_noise<FMT, V, NCALLS>(p, s, 2 * j + 1) : 0u;
           const float y0 = cast_one<FMT, RM>(load_elem16<DT>(w & 0xFFFFu), scale, rcp, r0);
           const float y1 = cast_one<FMT, RM>(load_elem16<DT>(w >> 16), scale, rcp, r1);
-          o[j] = (store_elem16<DT>(y0) & 0xFFFFu) | (store_elem16<DT>(y1) << 16);
+          o[j] = pack_pair16<DT>(y0, y1);
         }
       }
       store_stream(&out[v0 + (uint64_t)s * 64u], o);
@@ -252,8 +255,8 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
   if (((uintptr_t)in % es) || ((uintptr_t)out % es))
     return fail(FPEMU_EALIGN, "fpemu_cast: buffer not aligned to its element size");
 
-  // stochastic: 4 slots per wave (the noise layout's superblock); deterministic: 1
-  const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 64u * (rmode == STOCHASTIC ? 4u : 1u);
+  // slots per wave: see slots_per_wave()
+  const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 64u * (rmode == STOCHASTIC ? 4u : (dtype == FPEMU_F32 ? 1u : 2u));
   const bool vec_ok = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 &&
                       (rmode != STOCHASTIC || (prm.elem_base % sb_elems) == 0);
   const uint64_t nsb = vec_ok ? n / sb_elems : 0;

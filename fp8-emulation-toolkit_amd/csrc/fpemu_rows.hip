@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out
         }
         const float y0 = cast_one<FMT, RM>(load_elem16<DT>(v[j] & 0xFFFFu), scale, rcp, r0);
         const float y1 = cast_one<FMT, RM>(load_elem16<DT>(v[j] >> 16), scale, rcp, r1);
-        o[j] = (store_elem16<DT>(y0) & 0xFFFFu) | (store_elem16<DT>(y1) << 16);
+        o[j] = pack_pair16<DT>(y0, y1);
       }
     }
     vout[i] = o;
