@@ -36,6 +36,7 @@ namespace {
 constexpr int kDefaultMaxBlocks = 0x7FFFFFFF;  // cast: one superblock per wave, no loop
 constexpr int kAmaxMaxBlocks = 256 * 16;       // amax: looped, one atomic per block
 constexpr uint64_t kSmallTensor = 32768;       // <= this many elements: fused one-workgroup path
+constexpr uint64_t kKeepBytes = 160ull << 20;  // fused amax -> cast: tensors up to this size keep cache residency
 constexpr int kNoRowsKernel = -100;            // fpemu_rows_launch_: no kernel for this fmt/rmode/dtype
 
 int g_max_blocks = 0;
@@ -149,7 +150,15 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out
 // ---------------------------------------------------------------------------------------------
 constexpr int kAmaxVPT = 8;  // 16-byte vectors in flight per lane
 
-template <int DT>
+// KEEP = false: read-once stream (non-temporal loads).  KEEP = true: default cache policy, for the fused
+// amax -> cast of a tensor small enough to stay in the 256 MiB Infinity Cache: the cast's read of the
+// same bytes right afterwards is then served from cache instead of HBM.
+template <bool KEEP> __device__ __forceinline__ u32x4 amax_load(const u32x4 *p) {
+  if constexpr (KEEP) return *p;
+  else return __builtin_nontemporal_load(p);
+}
+
+template <int DT, bool KEEP>
 __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ in_, uint64_t nvec,
                                                       uint64_t n, uint32_t *amax_bits) {
   constexpr unsigned V = Storage<DT>::V;
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
     const uint64_t v0 = sb * (64u * U) + lane;
     u32x4 v[U];
 #pragma unroll
-    for (int k = 0; k < U; k++) v[k] = __builtin_nontemporal_load(&in[v0 + (uint64_t)k * 64u]);
+    for (int k = 0; k < U; k++) v[k] = amax_load<KEEP>(&in[v0 + (uint64_t)k * 64u]);
 #pragma unroll
     for (int k = 0; k < U; k++)
 #pragma unroll
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
   const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = nsb * (64u * U) + tid; i < nvec; i += stride) {
-    const u32x4 v = __builtin_nontemporal_load(&in[i]);
+    const u32x4 v = amax_load<KEEP>(&in[i]);
 #pragma unroll
     for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, v[j]);
   }
@@ -360,7 +369,7 @@ int fpemu_forward(const void *in, void *out, int dtype, const char *mode, uint64
   return fpemu_cast(in, out, size, dtype, fmt, rmode, scale, seed, offset, 0, stream);
 }
 
-int fpemu_amax(const void *in, uint64_t n, int dtype, uint32_t *amax_bits, void *stream) {
+static int launch_amax(const void *in, uint64_t n, int dtype, uint32_t *amax_bits, bool keep, void *stream) {
   if (n == 0) return FPEMU_OK;
   if (in == nullptr || amax_bits == nullptr) return fail(FPEMU_EINVAL, "fpemu_amax: null argument");
   if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_amax: bad dtype id");
@@ -376,14 +385,22 @@ int fpemu_amax(const void *in, uint64_t n, int dtype, uint32_t *amax_bits, void 
   if (blocks < rest_blocks) blocks = rest_blocks;
   if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
   if (blocks == 0) blocks = 1;
-  void (*fn)(const void *, uint64_t, uint64_t, uint32_t *) =
-      dtype == FPEMU_F32 ? amax_kernel<FPEMU_F32>
-                         : dtype == FPEMU_F16 ? amax_kernel<FPEMU_F16> : amax_kernel<FPEMU_BF16>;
+  typedef void (*amax_fn)(const void *, uint64_t, uint64_t, uint32_t *);
+  const amax_fn fn = keep ? (dtype == FPEMU_F32   ? (amax_fn)amax_kernel<FPEMU_F32, true>
+                             : dtype == FPEMU_F16 ? (amax_fn)amax_kernel<FPEMU_F16, true>
+                                                  : (amax_fn)amax_kernel<FPEMU_BF16, true>)
+                          : (dtype == FPEMU_F32   ? (amax_fn)amax_kernel<FPEMU_F32, false>
+                             : dtype == FPEMU_F16 ? (amax_fn)amax_kernel<FPEMU_F16, false>
+                                                  : (amax_fn)amax_kernel<FPEMU_BF16, false>);
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, in, nvec, n,
                      amax_bits);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
   return FPEMU_OK;
+}
+
+int fpemu_amax(const void *in, uint64_t n, int dtype, uint32_t *amax_bits, void *stream) {
+  return launch_amax(in, n, dtype, amax_bits, /*keep=*/false, stream);
 }
 
 int fpemu_cast_scaled(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
@@ -419,7 +436,9 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
   hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax_ws);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-  int rc = fpemu_amax(in, n, dtype, amax_ws, stream);
+  // the cast re-reads what the amax pass just read: let a tensor that fits the Infinity Cache stay there
+  const bool keep = dtype >= FPEMU_F32 && dtype <= FPEMU_BF16 && n * elem_size(dtype) <= kKeepBytes;
+  int rc = launch_amax(in, n, dtype, amax_ws, keep, stream);
   if (rc != FPEMU_OK) return rc;
   return fpemu_cast_scaled(in, out, n, dtype, fmt, rmode, amax_ws, flt_max, clamp, seed, offset, 0, stream);
 }
