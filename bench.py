@@ -254,6 +254,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0's extras run longer than the others': leave together
         dist.destroy_process_group()
 
 
