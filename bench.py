@@ -73,11 +73,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # (FPEMU_BENCH_BACKEND=gloo with all ranks on one GPU rehearses the multi-process flow on a 1-GPU box)
+    backend = os.environ.get("FPEMU_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mpemu.pytquant.hip import _binding as hip
 
@@ -116,7 +122,7 @@ def main():
     achieved = BYTES_PER_ELEM * n / (avg_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.isfile(tpath):
+    if os.path.isfile(tpath) and n == (1 << 28):  # the PMC passes were run on the default workload
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
