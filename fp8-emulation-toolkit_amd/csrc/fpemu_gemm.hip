@@ -364,10 +364,14 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, flo
         for (int j = 0; j < TW; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-    }
-    if (more) {
-      tile_store<A_KCONT, MBK, TB>(As[cur ^ 1], tid, pa);
-      tile_store<B_KCONT, MBK, TB>(Bs[cur ^ 1], tid, pb);
+      // The prefetched tile goes into the OTHER LDS buffer, which nobody reads during this iteration
+      // (every wave passed the barrier that ended the previous one), so its stores are issued in the
+      // shadow of the MFMAs, three quarters of the way through, instead of after them.
+      if (st == (3 * MBK) / 8 - 1 && more) {
+        tile_store<A_KCONT, MBK, TB>(As[cur ^ 1], tid, pa);
+        tile_store<B_KCONT, MBK, TB>(Bs[cur ^ 1], tid, pb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();
     cur ^= 1;
