@@ -1,0 +1,35 @@
+"""BASELINE config 3 timing: BERT-base (random init) forward, batch 8 x 128 tokens, plain vs
+mpt_emu.quantize_model(dtype="e4m3") post-training quantisation hooks."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "fp8-emulation-toolkit_amd"))
+from transformers import BertConfig, BertModel  # noqa: E402
+
+from mpemu import mpt_emu  # noqa: E402
+
+
+def run(model, ids, n):
+    with torch.no_grad():
+        for _ in range(3):
+            model(ids)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            model(ids)
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+torch.manual_seed(0)
+model = BertModel(BertConfig()).cuda().eval()
+ids = torch.randint(0, 30000, (8, 128), device="cuda")
+plain = run(model, ids, 20)
+model, emu = mpt_emu.quantize_model(model, dtype="e4m3", device="cuda")
+quant = run(model, ids, 20)
+print("BERT-base forward 8x128: plain %.2f ms, E4M3 PTQ hooks %.2f ms (x%.2f), hooked modules %d" % (
+    plain, quant, quant / plain, len(emu.emulator.model_qconfig_dict)))
