@@ -150,6 +150,20 @@ def _on_device(t):
 
 _mode_cache = {}
 
+# ---- optional profiler ranges (the reference marks its c-model ops with RECORD_FUNCTION,
+# cmodel/simple/simple_gemm.cpp:47; here every native entry can carry one) ---------------------
+_trace = os.environ.get("MPEMU_TRACE", "0") not in ("", "0")
+
+
+def set_tracing(on):
+    """Wrap each native call in a torch.profiler.record_function range (also MPEMU_TRACE=1)."""
+    global _trace
+    _trace = bool(on)
+
+
+def _range(name):
+    return torch.profiler.record_function(name) if _trace else _NOCTX
+
 
 # ---- stochastic-rounding stream state: (seed, per-call offset) -----------------------------
 _seed = 0x5EED0F8E3A11
@@ -223,7 +237,7 @@ def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None, clamp=True
     _require_device(dst, "output")
     if amax_ws is None:
         amax_ws = torch.empty(1, dtype=torch.int32, device=src.device)
-    with _on_device(src):
+    with _range("fpemu::quantize_per_tensor"), _on_device(src):
         _check(lib().fpemu_quantize_per_tensor(src.data_ptr(), dst.data_ptr(), src.numel(),
                                                _dtype_id(src), fmt, rmode, float(flt_max),
                                                int(bool(clamp)), amax_ws.data_ptr(), _seed, _next_offset(rmode),
@@ -243,7 +257,7 @@ def quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=True):
     off = _offset
     if rmode == STOCHASTIC:
         _offset += rows  # one call offset per row, as a loop of per-row casts would consume
-    with _on_device(src):
+    with _range("fpemu::quantize_rows"), _on_device(src):
         _check(lib().fpemu_quantize_rows(src.data_ptr(), dst.data_ptr(), rows, n // rows, _dtype_id(src),
                                          fmt, rmode, float(flt_max), int(bool(clamp)), _seed, off,
                                          _stream(src)))
@@ -265,7 +279,7 @@ def quantize_blocks_(src, dst, block_size, fmt, rmode):
     off = _offset
     if rmode == STOCHASTIC:
         _offset += n // block_size
-    with _on_device(src):
+    with _range("fpemu::quantize_blocks"), _on_device(src):
         _check(lib().fpemu_quantize_blocks(src.data_ptr(), dst.data_ptr(), n, block_size, _dtype_id(src), fmt,
                                            rmode, _seed, off, _stream(src)))
     return dst
@@ -290,7 +304,7 @@ def gemm_(C, A, B, alpha=1.0, a_trans=False, b_trans=False, variant=GEMM_FMA):
             (B.shape[1] if b_trans else B.shape[0]) != K:
         raise ValueError("fpemu gemm: shapes do not match: C %s, A %s (trans=%s), B %s (trans=%s)" % (
             tuple(C.shape), tuple(A.shape), a_trans, tuple(B.shape), b_trans))
-    with _on_device(C):
+    with _range("cmodel::simple_gemm"), _on_device(C):
         _check(lib().fpemu_gemm_f32(C.data_ptr(), A.data_ptr(), B.data_ptr(), M, N, K, A.shape[1], B.shape[1],
                                     C.shape[1], float(alpha), int(bool(a_trans)), int(bool(b_trans)),
                                     int(variant), _stream(C)))
@@ -324,7 +338,7 @@ def conv2d_fp_(output, input, weight, bias, stride, padding, variant=GEMM_FMA):
     OH, OW = (H + 2 * padding - R) // stride + 1, (W + 2 * padding - S) // stride + 1
     if C1 != C or tuple(output.shape) != (N, K, OH, OW) or (bias is not None and bias.numel() != K):
         raise ValueError("fpemu conv2d_fp: shapes do not match")
-    with _on_device(input):
+    with _range("cmodel::simple_conv2d_fp"), _on_device(input):
         ws, nbytes = _conv_ws(CONV_FP, dims, input)
         _check(lib().fpemu_conv2d_fp_f32(output.data_ptr(), input.data_ptr(), weight.data_ptr(),
                                          None if bias is None else bias.data_ptr(), *dims, int(variant),
@@ -341,7 +355,7 @@ def conv2d_bp_(grad_input, grad_output, weight, stride, padding, variant=GEMM_FM
     OH, OW = (H + 2 * padding - R) // stride + 1, (W + 2 * padding - S) // stride + 1
     if C1 != C or tuple(grad_output.shape) != (N, K, OH, OW):
         raise ValueError("fpemu conv2d_bp: shapes do not match")
-    with _on_device(grad_input):
+    with _range("cmodel::simple_conv2d_bp"), _on_device(grad_input):
         ws, nbytes = _conv_ws(CONV_BP, dims, grad_input)
         _check(lib().fpemu_conv2d_bp_f32(grad_input.data_ptr(), grad_output.data_ptr(), weight.data_ptr(), *dims,
                                          int(variant), ws.data_ptr(), nbytes, _stream(grad_input)))
@@ -357,7 +371,7 @@ def conv2d_wu_(grad_weight, grad_output, input, stride, padding, variant=GEMM_FM
     OH, OW = (H + 2 * padding - R) // stride + 1, (W + 2 * padding - S) // stride + 1
     if C1 != C or tuple(grad_output.shape) != (N, K, OH, OW):
         raise ValueError("fpemu conv2d_wu: shapes do not match")
-    with _on_device(input):
+    with _range("cmodel::simple_conv2d_wu"), _on_device(input):
         ws, nbytes = _conv_ws(CONV_WU, dims, input)
         _check(lib().fpemu_conv2d_wu_f32(grad_weight.data_ptr(), grad_output.data_ptr(), input.data_ptr(), *dims,
                                          int(variant), ws.data_ptr(), nbytes, _stream(input)))
@@ -375,7 +389,7 @@ def forward(input, mode, size, inplace, scale, block_norm=False, block_size=1):
     n, bs = input.numel(), int(block_size)
     if block_norm and bs > 0 and n > 0 and (bs == n or n % bs == 0) and fmt in _BLOCKNORM_FMTS:
         return [quantize_blocks_(input, out, bs, fmt, rmode)]  # cpp:2020-2025: otherwise demoted
-    with _on_device(input):
+    with _range("fpemu::forward"), _on_device(input):
         _check(lib().fpemu_forward(input.data_ptr(), out.data_ptr(), _dtype_id(input), str(mode).encode(),
                                    input.numel(), float(scale), 0, 1,
                                    _seed, _next_offset(rmode), _stream(input)))

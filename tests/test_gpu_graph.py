@@ -57,3 +57,22 @@ def test_cast_quantize_gemm_under_graph_capture():
         assert_bits_equal(z.cpu().numpy(), orc.cast(hx, "E4M3_RNE", scale=sc), "graph per-tensor quantise",
                           nan_payload_ok=True)
         assert_bits_equal(c.cpu().numpy(), orc.gemm(ha, hb, fused=True), "graph gemm")
+
+
+def test_profiler_ranges_when_tracing_is_on():
+    """MPEMU_TRACE / set_tracing: native calls carry torch.profiler ranges (the reference marks its c-model
+    ops with RECORD_FUNCTION)."""
+    from mpemu.pytquant.hip import _binding as hip
+
+    x = torch.randn(4096, device=DEV)
+    a = torch.randn(64, 64, device=DEV)
+    c = torch.zeros(64, 64, device=DEV)
+    hip.set_tracing(True)
+    try:
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+            hip.forward(x, "E4M3_RNE", x.numel(), False, 1.0)
+            hip.gemm_(c, a, a)
+        names = {e.name for e in prof.events()}
+    finally:
+        hip.set_tracing(False)
+    assert "fpemu::forward" in names and "cmodel::simple_gemm" in names
