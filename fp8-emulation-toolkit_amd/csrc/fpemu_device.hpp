@@ -212,8 +212,10 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t ctr, ui
   uint32_t c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
 #pragma unroll
   for (int r = 0; r < 10; r++) {
-    const uint32_t h0 = __umulhi(M0, c0), l0 = M0 * c0;
-    const uint32_t h1 = __umulhi(M1, c2), l1 = M1 * c2;
+    // one 32x32->64 multiply per product (v_mad_u64_u32) instead of a mul_hi / mul_lo pair
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+    const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
     const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
     c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     k0 += W0; k1 += W1;
