@@ -37,6 +37,7 @@ constexpr int kDefaultMaxBlocks = 0x7FFFFFFF;  // cast: one superblock per wave,
 constexpr int kAmaxMaxBlocks = 256 * 16;       // amax: looped, one atomic per block
 constexpr uint64_t kSmallTensor = 32768;       // <= this many elements: fused one-workgroup path
 constexpr uint64_t kKeepBytes = 160ull << 20;  // fused amax -> cast: tensors up to this size keep cache residency
+constexpr uint64_t kMaxPartials = 256;  // one per CU; measured best of 128 / 256 / 512 / 1024 / 2048
 constexpr int kNoRowsKernel = -100;            // fpemu_rows_launch_: no kernel for this fmt/rmode/dtype
 
 int g_max_blocks = 0;
@@ -55,6 +56,9 @@ struct CastParams {
   int clamp;
   uint64_t seed, offset;
   uint64_t elem_base;         // global index of element 0 of this buffer
+  const uint32_t *partials;   // npart > 0: per-block maxima of a preceding amax_kernel<.., PARTIAL> launch;
+  uint32_t npart;             //            every block reduces them itself (no atomics, no pre-zeroed word)
+  uint32_t *amax_pub;         //            and block 0 publishes the maximum here
 };
 
 // Random bits for element e (0..V-1) of slot s from the lane's Philox results of this superblock.
@@ -81,7 +85,23 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out
   constexpr int NCALLS = SR ? (int)(4u * V * noise_bytes<FMT>() / 16u) : 1;
 
   float scale = prm.scale, rcp = prm.rcp;
-  if (prm.amax_bits != nullptr) {
+  if (prm.npart != 0u) {  // uniform over the launch
+    __shared__ uint32_t pmax[kWavesPerBlock];
+    uint32_t m = 0u;
+    for (uint32_t i = threadIdx.x; i < prm.npart; i += kBlock) {
+      const uint32_t v = prm.partials[i];
+      m = m > v ? m : v;
+    }
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63u) == 0u) pmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    uint32_t r = pmax[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; w++) r = r > pmax[w] ? r : pmax[w];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *prm.amax_pub = r;
+    scale = scale_from_amax(r, prm.flt_max, prm.clamp != 0);
+    rcp = scale_reciprocal(scale);
+  } else if (prm.amax_bits != nullptr) {
     scale = scale_from_amax(*prm.amax_bits, prm.flt_max, prm.clamp != 0);
     rcp = scale_reciprocal(scale);
   }
@@ -158,7 +178,9 @@ template <bool KEEP> __device__ __forceinline__ u32x4 amax_load(const u32x4 *p) 
   else return __builtin_nontemporal_load(p);
 }
 
-template <int DT, bool KEEP>
+// PARTIAL = true: instead of the atomic, block b stores its maximum to amax_bits[b] (the two-launch
+// per-tensor path for mid-size tensors: no word to zero first, no atomics; cast_kernel reduces them).
+template <int DT, bool KEEP, bool PARTIAL>
 __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ in_, uint64_t nvec,
                                                       uint64_t n, uint32_t *amax_bits) {
   constexpr unsigned V = Storage<DT>::V;
@@ -205,6 +227,10 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
     // storage pattern -> fp32 pattern (order preserving; NaN stays above +Inf)
     if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
     else if constexpr (DT == FPEMU_BF16) r = r << 16;
+    if constexpr (PARTIAL) {
+      amax_bits[blockIdx.x] = r;
+      return;
+    }
     // The running maximum only grows, so a block whose maximum does not beat the value already
     // published can skip its atomic: after the first wave of blocks almost all do, which keeps
     // tens of thousands of blocks off the single word.  (A stale read only costs a redundant atomic.)
@@ -351,6 +377,9 @@ int fpemu_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rm
   prm.seed = seed;
   prm.offset = offset;
   prm.elem_base = elem_base;
+  prm.partials = nullptr;
+  prm.npart = 0;
+  prm.amax_pub = nullptr;
   return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
 }
 
@@ -386,12 +415,12 @@ static int launch_amax(const void *in, uint64_t n, int dtype, uint32_t *amax_bit
   if (blocks > 0x7FFFFFFFull) blocks = 0x7FFFFFFFull;
   if (blocks == 0) blocks = 1;
   typedef void (*amax_fn)(const void *, uint64_t, uint64_t, uint32_t *);
-  const amax_fn fn = keep ? (dtype == FPEMU_F32   ? (amax_fn)amax_kernel<FPEMU_F32, true>
-                             : dtype == FPEMU_F16 ? (amax_fn)amax_kernel<FPEMU_F16, true>
-                                                  : (amax_fn)amax_kernel<FPEMU_BF16, true>)
-                          : (dtype == FPEMU_F32   ? (amax_fn)amax_kernel<FPEMU_F32, false>
-                             : dtype == FPEMU_F16 ? (amax_fn)amax_kernel<FPEMU_F16, false>
-                                                  : (amax_fn)amax_kernel<FPEMU_BF16, false>);
+  const amax_fn fn = keep ? (dtype == FPEMU_F32   ? (amax_fn)amax_kernel<FPEMU_F32, true, false>
+                             : dtype == FPEMU_F16 ? (amax_fn)amax_kernel<FPEMU_F16, true, false>
+                                                  : (amax_fn)amax_kernel<FPEMU_BF16, true, false>)
+                          : (dtype == FPEMU_F32   ? (amax_fn)amax_kernel<FPEMU_F32, false, false>
+                             : dtype == FPEMU_F16 ? (amax_fn)amax_kernel<FPEMU_F16, false, false>
+                                                  : (amax_fn)amax_kernel<FPEMU_BF16, false, false>);
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, in, nvec, n,
                      amax_bits);
   hipError_t e = hipGetLastError();
@@ -416,6 +445,9 @@ int fpemu_cast_scaled(const void *in, void *out, uint64_t n, int dtype, int fmt,
   prm.seed = seed;
   prm.offset = offset;
   prm.elem_base = elem_base;
+  prm.partials = nullptr;
+  prm.npart = 0;
+  prm.amax_pub = nullptr;
   return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
 }
 
@@ -441,6 +473,47 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
   int rc = launch_amax(in, n, dtype, amax_ws, keep, stream);
   if (rc != FPEMU_OK) return rc;
   return fpemu_cast_scaled(in, out, n, dtype, fmt, rmode, amax_ws, flt_max, clamp, seed, offset, 0, stream);
+}
+
+int fpemu_quantize_per_tensor_ws(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
+                                 float flt_max, int clamp, uint32_t *ws, uint64_t ws_words, uint64_t seed,
+                                 uint64_t offset, void *stream) {
+  if (ws == nullptr || ws_words < 1) return fail(FPEMU_EINVAL, "fpemu_quantize_per_tensor_ws: null workspace");
+  if (n == 0) return FPEMU_OK;
+  const bool args_ok = in != nullptr && out != nullptr && dtype >= FPEMU_F32 && dtype <= FPEMU_BF16 &&
+                       ((uintptr_t)in % elem_size(dtype)) == 0 && ((uintptr_t)out % elem_size(dtype)) == 0;
+  // above the one-workgroup size: two launches -- per-block maxima into ws[1..], then the cast, whose
+  // blocks each reduce those maxima (L2 hits) -- instead of zero + atomic amax + cast
+  if (args_ok && n > kSmallTensor && ws_words >= 2 &&
+      pick_cast_dt(dtype, fmt, rmode) != nullptr && fmt != BF16 && fmt != FP16 && fmt != FP16_DAZ) {
+    const bool vec_ok = ((uintptr_t)in % 16u) == 0;
+    const uint64_t nvec = vec_ok ? n / vec_elems(dtype) : 0;
+    uint64_t nb = vec_ok ? nvec / 256u : n / 1024u;   // >= one vector (or four elements) per thread
+    if (nb > kMaxPartials) nb = kMaxPartials;
+    if (nb > ws_words - 1) nb = ws_words - 1;
+    if (nb < 1) nb = 1;
+    typedef void (*amax_fn)(const void *, uint64_t, uint64_t, uint32_t *);
+    const amax_fn fn = dtype == FPEMU_F32   ? (amax_fn)amax_kernel<FPEMU_F32, true, true>
+                       : dtype == FPEMU_F16 ? (amax_fn)amax_kernel<FPEMU_F16, true, true>
+                                            : (amax_fn)amax_kernel<FPEMU_BF16, true, true>;
+    hipLaunchKernelGGL(fn, dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, in, nvec, n, ws + 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    CastParams prm;
+    prm.scale = 1.f;
+    prm.rcp = 1.f;
+    prm.amax_bits = nullptr;
+    prm.flt_max = flt_max;
+    prm.clamp = clamp;
+    prm.seed = seed;
+    prm.offset = offset;
+    prm.elem_base = 0;
+    prm.partials = ws + 1;
+    prm.npart = (uint32_t)nb;
+    prm.amax_pub = ws;
+    return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
+  }
+  return fpemu_quantize_per_tensor(in, out, n, dtype, fmt, rmode, flt_max, clamp, ws, seed, offset, stream);
 }
 
 int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt,

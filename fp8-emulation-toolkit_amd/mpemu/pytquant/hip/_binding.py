@@ -58,6 +58,8 @@ def lib():
         L.fpemu_cast_scaled.argtypes = [vp, vp, u64, i32, i32, i32, vp, f32, i32, u64, u64, u64, vp]
         L.fpemu_quantize_per_tensor.restype = i32
         L.fpemu_quantize_per_tensor.argtypes = [vp, vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, vp]
+        L.fpemu_quantize_per_tensor_ws.restype = i32
+        L.fpemu_quantize_per_tensor_ws.argtypes = [vp, vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, u64, vp]
         L.fpemu_quantize_rows.restype = i32
         L.fpemu_quantize_rows.argtypes = [vp, vp, u64, u64, i32, i32, i32, f32, i32, u64, u64, vp]
         i64 = ctypes.c_int64
@@ -77,7 +79,7 @@ def lib():
         L.fpemu_set_max_blocks.argtypes = [i32]
         L.fpemu_quantize_blocks.restype = i32
         L.fpemu_quantize_blocks.argtypes = [vp, vp, u64, u64, i32, i32, i32, u64, u64, vp]
-        if L.fpemu_abi_version() != 3:
+        if L.fpemu_abi_version() != 4:
             raise ImportError("libfpemu_hip.so: ABI version mismatch")
         _lib = L
     return _lib
@@ -231,17 +233,34 @@ def cast_scaled_(src, dst, fmt, rmode, amax_bits, flt_max, clamp=True, seed=None
     return dst
 
 
+_WS_WORDS = 1 + 256
+_ws_cache = {}
+
+
+def _stream_workspace(t, stream):
+    """Scratch words for the per-tensor path, one buffer per (device, stream): calls on one stream are
+    ordered, calls on different streams must not share scratch."""
+    key = (t.device.index, stream)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = _ws_cache[key] = torch.empty(_WS_WORDS, dtype=torch.int32, device=t.device)
+    return ws
+
+
 def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None, clamp=True):
-    """Fused amax -> device-side scale -> cast (qutils.py:282-287), no host sync."""
+    """Fused amax -> device-side scale -> cast (qutils.py:282-287), no host sync.  amax_ws: int32 tensor
+    whose word 0 receives the amax bit pattern (1 word, or more to serve as scratch); default: a cached
+    per-stream scratch buffer."""
     _require_device(src)
     _require_device(dst, "output")
-    if amax_ws is None:
-        amax_ws = torch.empty(1, dtype=torch.int32, device=src.device)
     with _range("fpemu::quantize_per_tensor"), _on_device(src):
-        _check(lib().fpemu_quantize_per_tensor(src.data_ptr(), dst.data_ptr(), src.numel(),
-                                               _dtype_id(src), fmt, rmode, float(flt_max),
-                                               int(bool(clamp)), amax_ws.data_ptr(), _seed, _next_offset(rmode),
-                                               _stream(src)))
+        stream = _stream(src)
+        if amax_ws is None:
+            amax_ws = _stream_workspace(src, stream)
+        _check(lib().fpemu_quantize_per_tensor_ws(src.data_ptr(), dst.data_ptr(), src.numel(), _dtype_id(src),
+                                                  fmt, rmode, float(flt_max), int(bool(clamp)),
+                                                  amax_ws.data_ptr(), amax_ws.numel(), _seed,
+                                                  _next_offset(rmode), stream))
     return dst
 
 

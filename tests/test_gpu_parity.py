@@ -374,3 +374,34 @@ def test_over_2g_elements_64bit_indexing(hip):
             hip.amax_(x, ws)
             assert ws.view(torch.float32).item() == max(float(x[i:i + step].abs().max()) for i in range(0, n, step))
         del y
+
+
+@pytest.mark.parametrize("n", [32769, 100003, 786432, (1 << 22), (1 << 22) + 1, 5000000])
+@pytest.mark.parametrize("mode", ["E4M3_RNE", "E5M2_STOCHASTIC"])
+def test_per_tensor_workspace_path_equals_single_word_path(hip, n, mode):
+    """fpemu_quantize_per_tensor_ws (two launches through per-block maxima for mid-size tensors) gives the
+    bits of the single-word path and of the oracle, publishes the amax in ws[0], needs no initialised
+    scratch, and works on a 4-byte-aligned view."""
+    fmt, rm = hip.parse_mode(mode)
+    fmax = FLT_MAX[mode.split("_")[0]]
+    x = mixed_inputs(n + 1, seed=n % 1000)
+    x[np.isnan(x)] = 2.5
+    for start in (0, 1):
+        hx = x[start:start + n]
+        t = torch.from_numpy(x).to(DEV)[start:start + n]
+        want = orc.cast(hx, mode, scale=orc.scale_from_amax(orc.amax(hx), fmax), seed=5, offset=0)
+        ws = torch.full((513,), 0x7F7FFFFF, dtype=torch.int32, device=DEV)     # garbage scratch
+        o1 = torch.empty(n, device=DEV)
+        hip.manual_seed(5)
+        hip.quantize_per_tensor_(t, o1, fmt, rm, fmax, amax_ws=ws)
+        assert_bits_equal(o1.cpu().numpy(), want, "%s n=%d start=%d workspace path" % (mode, n, start))
+        assert ws[:1].view(torch.float32).item() == float(orc.amax(hx))
+        w1 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        o2 = torch.empty(n, device=DEV)
+        hip.manual_seed(5)
+        hip.quantize_per_tensor_(t, o2, fmt, rm, fmax, amax_ws=w1)
+        assert torch.equal(o1.view(torch.int32), o2.view(torch.int32))
+        hip.manual_seed(5)
+        o3 = torch.empty(n, device=DEV)
+        hip.quantize_per_tensor_(t, o3, fmt, rm, fmax)                          # cached per-stream scratch
+        assert torch.equal(o1.view(torch.int32), o3.view(torch.int32))
