@@ -152,6 +152,17 @@ def main():
                                        "GB/s_per_gpu": round(12 * n / (s_avg * 1e-3) / 1e9, 1),
                                        "collective": "all_reduce(max) of 4 B" if world > 1 else "none"}
 
+        if world == 1:
+            # the local fused form (no collective): per-block maxima + cast, two launches
+            def fused_step():
+                hip.quantize_per_tensor_(x, y, fmt, rm, 448.0)
+
+            for _ in range(3):
+                fused_step()
+            f_avg, _ = time_launches(fused_step, 10)
+            extras["fused_per_tensor"] = {"ms_per_step": round(f_avg, 5),
+                                          "GB/s_per_gpu": round(12 * n / (f_avg * 1e-3) / 1e9, 1)}
+
         def inplace_step():
             hip.cast_(y, y, fmt, rm, scale=1.0)
 
