@@ -76,3 +76,25 @@ def test_profiler_ranges_when_tracing_is_on():
     finally:
         hip.set_tracing(False)
     assert "fpemu::forward" in names and "cmodel::simple_gemm" in names
+
+
+def test_graphed_forward_of_a_hooked_model():
+    """mpemu.graphs.GraphedForward: a whole E4M3-hooked forward replayed as one graph gives the bits of the
+    eager hooked forward, on the example input and on new data."""
+    from mpemu import mpt_emu
+    from mpemu.graphs import GraphedForward
+
+    torch.manual_seed(1)
+    model = torch.nn.Sequential(torch.nn.Linear(96, 192), torch.nn.GELU(), torch.nn.Linear(192, 96),
+                                torch.nn.LayerNorm(96)).to(DEV).eval()
+    model, _ = mpt_emu.quantize_model(model, dtype="e4m3", device="cuda")
+    x0 = torch.randn(300, 96, device=DEV)
+    fwd = GraphedForward(model, x0)
+    for seed in (0, 1, 2):
+        x = x0 if seed == 0 else torch.randn(300, 96, device=DEV, generator=torch.Generator(DEV).manual_seed(seed)) * 3
+        with torch.no_grad():
+            want = model(x).clone()
+        got = fwd(x)
+        assert torch.equal(want.view(torch.int32), got.view(torch.int32)), seed
+    with pytest.raises(ValueError):
+        fwd(torch.randn(10, 96, device=DEV))
