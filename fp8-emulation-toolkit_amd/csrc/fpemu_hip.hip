@@ -73,13 +73,13 @@ __device__ __forceinline__ uint32_t lane_noise(const Philox4 (&p)[NCALLS], unsig
 // 16-byte vectors per lane: 4 for stochastic modes (the noise layout's superblock); deterministic fp32
 // storage 1 (pure stream, measured fastest); deterministic 16-bit storage 2 (twice the ALU work per byte:
 // a second independent vector per lane hides it)
-template <int RM, int DT> constexpr int slots_per_wave() { return RM == STOCHASTIC ? 4 : (DT == FPEMU_F32 ? 1 : 2); }
+constexpr int slots_per_wave(int rm, int dt) { return rm == STOCHASTIC ? 4 : (dt == FPEMU_F32 ? 1 : 2); }
 
 template <int FMT, int RM, int DT>
 __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out_,
                                                       uint64_t nsb, uint64_t n, CastParams prm) {
   constexpr unsigned V = Storage<DT>::V;
-  constexpr int U = slots_per_wave<RM, DT>();
+  constexpr int U = slots_per_wave(RM, DT);
   constexpr uint64_t SB_ELEMS = (uint64_t)V * 64u * U;
   constexpr bool SR = (RM == STOCHASTIC);
   constexpr int NCALLS = SR ? (int)(4u * V * noise_bytes<FMT>() / 16u) : 1;
@@ -290,8 +290,7 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
   if (((uintptr_t)in % es) || ((uintptr_t)out % es))
     return fail(FPEMU_EALIGN, "fpemu_cast: buffer not aligned to its element size");
 
-  // slots per wave: see slots_per_wave()
-  const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 64u * (rmode == STOCHASTIC ? 4u : (dtype == FPEMU_F32 ? 1u : 2u));
+  const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 64u * (unsigned)slots_per_wave(rmode, dtype);
   const bool vec_ok = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 &&
                       (rmode != STOCHASTIC || (prm.elem_base % sb_elems) == 0);
   const uint64_t nsb = vec_ok ? n / sb_elems : 0;

@@ -164,7 +164,10 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
   if (fn == nullptr) return -100;  // kNoRowsKernel of fpemu_hip.hip
   const uint64_t per_block = team == 1 ? (uint64_t)kBlock : team == 64 ? (uint64_t)kWavesPerBlock : 1u;
   const uint64_t blocks = (rows + per_block - 1) / per_block;
-  if (blocks > 0x7FFFFFFFull) return FPEMU_EINVAL;
+  if (blocks > 0x7FFFFFFFull) {
+    fpemu_set_error_("fpemu rows: more than 2^31-1 workgroups");
+    return FPEMU_EINVAL;
+  }
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, in, out, rows, cols,
                      flt_max, policy, seed, offset, amax_out);
   hipError_t e = hipGetLastError();
