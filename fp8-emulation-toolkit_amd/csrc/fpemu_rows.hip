@@ -16,6 +16,13 @@
 // teams), every thread derives the row's scale, pass 2 re-reads and casts.  VEC = rows are 16-byte
 // aligned (cols % V == 0).  Stochastic noise: row r is "call offset + r", element index = column, exactly
 // what a loop of per-row casts with consecutive offsets draws.
+//
+// Rows that are 16-byte aligned and short enough to sit in registers (<= 8 vectors per lane of a
+// 256-thread team: 8192 fp32 / 16384 16-bit elements) take rows_reg_kernel instead: ONE read of the
+// row (non-temporal), the maximum reduced over the row's lane group, the held vectors cast and streamed
+// out -- a per-row quantisation at the flat cast's traffic.  The lane group is the smallest power of
+// two covering the row's vectors (4 lanes for a 16-element fp32 block ... a wave ... the block), so a
+// wave's load instruction still covers one contiguous run of rows.
 #include "fpemu_common.hpp"
 
 using namespace fpemu;
@@ -122,6 +129,116 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out
   }
 }
 
+// Register-resident rows: nv 16-byte vectors per row, a group of G = 1 << lg lanes per row (G <= 256),
+// NV >= ceil(nv / G) vectors held per lane, kBlock / G rows per workgroup.  Straight-line code: slots past
+// the row (or rows past the end) load a valid dummy address and are masked with selects, so the held
+// vectors stay plain registers; no thread leaves early (the block-wide team has a barrier).
+constexpr int kRegVecs = 8;
+
+template <int FMT, int RM, int DT, int NV>
+__global__ __launch_bounds__(kBlock) void rows_reg_kernel(const void *in_, void *out_, uint64_t rows,
+                                                          uint32_t nv, uint32_t lg, float flt_max, int policy,
+                                                          uint64_t seed, uint64_t offset, uint32_t *amax_out) {
+  constexpr unsigned V = Storage<DT>::V;
+  constexpr bool SR = (RM == STOCHASTIC);
+  const unsigned G = 1u << lg;
+  const unsigned t = threadIdx.x & (G - 1u);
+  const uint64_t row = (((uint64_t)blockIdx.x * kBlock) >> lg) + (threadIdx.x >> lg);
+  const bool live = row < rows;
+  const u32x4 *vin = reinterpret_cast<const u32x4 *>(in_) + (live ? row : 0) * nv;
+  u32x4 *vout = reinterpret_cast<u32x4 *>(out_) + row * nv;
+  const bool bn = (policy == kRowsBlockNorm);
+
+  u32x4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const uint32_t i = (uint32_t)k * G + t;
+    v[k] = __builtin_nontemporal_load(&vin[i < nv ? i : 0u]);
+  }
+  uint32_t m = 0u;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const bool ok = live && (uint32_t)k * G + t < nv;
+    uint32_t mk = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) mk = absmax_word<DT>(mk, bn ? drop_nan<DT>(v[k][j]) : v[k][j]);
+    mk = ok ? mk : 0u;
+    m = m > mk ? m : mk;
+  }
+  // butterfly over the row's lanes (G is uniform: scalar branches)
+#pragma unroll
+  for (unsigned off = 1; off < 64u; off <<= 1) {
+    if (off < G) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)m, (int)off, 64);
+      m = m > o ? m : o;
+    }
+  }
+  uint32_t r = m;
+  if (G == (unsigned)kBlock) {
+    __shared__ uint32_t part[kWavesPerBlock];
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = r;
+    __syncthreads();
+    r = part[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; w++) r = r > part[w] ? r : part[w];
+  }
+  if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
+  else if constexpr (DT == FPEMU_BF16) r = r << 16;
+  if (amax_out != nullptr && t == 0u && live) amax_out[row] = r;
+  const float scale = bn ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
+  const float rcp = scale_reciprocal(scale);
+  const uint64_t roff = offset + row;
+
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const uint32_t i = (uint32_t)k * G + t;
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if constexpr (DT == FPEMU_F32) {
+        uint32_t rnd = 0u;
+        if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, (uint64_t)i * V + j);
+        o[j] = f2u(cast_one<FMT, RM>(u2f(v[k][j]), scale, rcp, rnd));
+      } else {
+        uint32_t r0 = 0u, r1 = 0u;
+        if constexpr (SR) {
+          r0 = rand_bits_elem<FMT, V>(seed, roff, (uint64_t)i * V + 2 * j);
+          r1 = rand_bits_elem<FMT, V>(seed, roff, (uint64_t)i * V + 2 * j + 1);
+        }
+        const float y0 = cast_one<FMT, RM>(load_elem16<DT>(v[k][j] & 0xFFFFu), scale, rcp, r0);
+        const float y1 = cast_one<FMT, RM>(load_elem16<DT>(v[k][j] >> 16), scale, rcp, r1);
+        o[j] = pack_pair16<DT>(y0, y1);
+      }
+    }
+    if (live && i < nv) store_stream(&vout[i], o);
+  }
+}
+
+typedef void (*rows_reg_fn)(const void *, void *, uint64_t, uint32_t, uint32_t, float, int, uint64_t, uint64_t,
+                            uint32_t *);
+
+template <int DT, int NV> rows_reg_fn pick_rows_reg(int fmt, int rm) {
+#define FPEMU_CASE(F, R) \
+  if (fmt == F && rm == R) return rows_reg_kernel<F, R, DT, NV>;
+  FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
+  FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
+  FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
+  FPEMU_CASE(E5M2_DAZ, RNTZ)
+  FPEMU_CASE(E4M3, RTZ) FPEMU_CASE(E4M3, RNE) FPEMU_CASE(E4M3, STOCHASTIC)
+  FPEMU_CASE(E3M4, RTZ) FPEMU_CASE(E3M4, RNE) FPEMU_CASE(E3M4, STOCHASTIC)
+  FPEMU_CASE(E4M3_IEEE, RNE) FPEMU_CASE(E4M3_IEEE, STOCHASTIC)
+  FPEMU_CASE(FP4, RNE)
+#undef FPEMU_CASE
+  return nullptr;
+}
+
+template <int DT> rows_reg_fn pick_rows_reg_nv(uint32_t per_lane, int fmt, int rm) {
+  return per_lane <= 1 ? pick_rows_reg<DT, 1>(fmt, rm)
+       : per_lane <= 2 ? pick_rows_reg<DT, 2>(fmt, rm)
+       : per_lane <= 4 ? pick_rows_reg<DT, 4>(fmt, rm)
+                       : pick_rows_reg<DT, kRegVecs>(fmt, rm);
+}
+
 typedef void (*rows_fn)(const void *, void *, uint64_t, uint64_t, float, int, uint64_t, uint64_t, uint32_t *);
 
 template <int DT, bool VEC, int TEAM> rows_fn pick_rows(int fmt, int rm) {
@@ -141,7 +258,7 @@ template <int DT, bool VEC, int TEAM> rows_fn pick_rows(int fmt, int rm) {
 
 template <int DT> rows_fn pick_rows_dt(bool vec, int team, int fmt, int rm) {
   if (team == 1) return pick_rows<DT, false, 1>(fmt, rm);
-  if (team == 64) return vec ? pick_rows<DT, true, 64>(fmt, rm) : pick_rows<DT, false, 64>(fmt, rm);
+  if (team == 64) return pick_rows<DT, false, 64>(fmt, rm);  // aligned short rows take rows_reg_kernel
   return vec ? pick_rows<DT, true, kBlock>(fmt, rm) : pick_rows<DT, false, kBlock>(fmt, rm);
 }
 
@@ -153,6 +270,36 @@ template <int DT> rows_fn pick_rows_dt(bool vec, int team, int fmt, int rm) {
 extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype,
                                   int fmt, int rmode, float flt_max, int policy, uint64_t seed,
                                   uint64_t offset, uint32_t *amax_out, int force_block, void *stream) {
+  // register-resident path: aligned rows of at most kBlock * kRegVecs vectors
+  const unsigned ve = vec_elems(dtype);
+  if ((((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % ve) == 0 && cols / ve <= (uint64_t)kBlock * kRegVecs) {
+    const uint32_t nv = (uint32_t)(cols / ve);
+    // lane group: the smallest power of two covering the row's vectors, up to a wave; longer rows keep the
+    // wave (<= 4 vectors per lane) or take the whole block; a lone row is spread over the block
+    uint32_t lg = 0;
+    if (nv > 256u || ((force_block || rows == 1) && nv > 64u)) lg = 8;
+    else if (nv > 64u) lg = 6;
+    else while ((1u << lg) < nv) lg++;
+    const uint32_t per_lane = (nv + (1u << lg) - 1u) >> lg;
+    rows_reg_fn rf = dtype == FPEMU_F32 ? pick_rows_reg_nv<FPEMU_F32>(per_lane, fmt, rmode)
+                   : dtype == FPEMU_F16 ? pick_rows_reg_nv<FPEMU_F16>(per_lane, fmt, rmode)
+                   : dtype == FPEMU_BF16 ? pick_rows_reg_nv<FPEMU_BF16>(per_lane, fmt, rmode) : nullptr;
+    if (rf == nullptr) return -100;  // kNoRowsKernel of fpemu_hip.hip
+    const uint64_t per_blk = (uint64_t)kBlock >> lg;
+    const uint64_t nblk = (rows + per_blk - 1) / per_blk;
+    if (nblk > 0x7FFFFFFFull) {
+      fpemu_set_error_("fpemu rows: more than 2^31-1 workgroups");
+      return FPEMU_EINVAL;
+    }
+    hipLaunchKernelGGL(rf, dim3((unsigned)nblk), dim3(kBlock), 0, (hipStream_t)stream, in, out, rows, nv, lg,
+                       flt_max, policy, seed, offset, amax_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      fpemu_set_error_(hipGetErrorString(e));
+      return (int)e;
+    }
+    return FPEMU_OK;
+  }
   const int team = (force_block || rows == 1 || cols > kWaveRowCols) ? kBlock : cols > kLaneRowCols ? 64 : 1;
   // 16-byte accesses only when every lane of the team gets at least one vector; shorter rows go one
   // element per lane (still one coalesced segment per wave, and no idle lanes)

@@ -116,6 +116,31 @@ def test_blocknorm_team_shapes_vs_oracle(hip, mode, bs):
         assert hip.get_rng_state() == (21, nb)  # one call offset per block
 
 
+@pytest.mark.parametrize("mode", ["E4M3_RNE", "E5M2_STOCHASTIC", "FP4_NEAREST"])
+@pytest.mark.parametrize("bs", [4, 8, 12, 32, 64, 128, 256, 260, 576, 2048, 4096, 4100, 8192, 8196])
+def test_blocknorm_register_kernel_shapes(hip, mode, bs):
+    """16-byte-aligned blocks up to 8192 fp32 elements are held in registers by a lane group of 1..256
+    lanes (one read of the data); every group size, partial last slots and the hand-over to the two-pass
+    kernel at 8196."""
+    nb = 37 if bs <= 2048 else 5
+    x = mixed_inputs(bs * nb, seed=1000 + bs)
+    hip.manual_seed(9)
+    t = torch.from_numpy(x).to(DEV)
+    got = hip.forward(t, mode, t.numel(), False, 1.0, True, bs)[0].cpu().numpy()
+    assert_bits_equal(got, orc.cast_blocknorm(x, mode, bs, seed=9, offset=0), "%s bs=%d" % (mode, bs),
+                      nan_payload_ok=True)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bs", [8, 64, 520, 4096, 16384, 16392])
+def test_blocknorm_register_kernel_16bit_storage(hip, dt, bs):
+    nb = 11
+    t = (torch.randn(bs * nb, device=DEV, generator=torch.Generator(device=DEV).manual_seed(bs)) * 5).to(dt)
+    got = hip.forward(t, "E4M3_RNE", t.numel(), False, 1.0, True, bs)[0]
+    want = torch.from_numpy(orc.cast_blocknorm(t.float().cpu().numpy(), "E4M3_RNE", bs)).to(dt)
+    assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16)), (dt, bs)
+
+
 def test_emb_norm_call_shape(hip):
     """hybrid_emu.py:119 calls FPEmuOp.apply(param, mode, True, emb_norm, cols): positional slots make that
     scale=True, blocknorm=cols (truthy), blocksize=1 -- block norm with one element per block."""

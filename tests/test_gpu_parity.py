@@ -282,7 +282,7 @@ def test_device_scale_random_amax_sweep(hip):
 # rows kernel: per-channel / fine-grained scaling in one launch
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("rows,cols", [(1, 1), (3, 7), (64, 147), (17, 1024), (768, 768), (5, 70001),
-                                       (3072, 768), (2, 262144)])
+                                       (3072, 768), (2, 262144), (1000, 36), (37, 2304), (9, 8192)])
 @pytest.mark.parametrize("mode,clamp", [("E4M3_RNE", True), ("E5M2_RNE", True), ("E3M4_RNE", False),
                                         ("E5M2_STOCHASTIC", True), ("E4M3_RTZ", False)])
 def test_rows_kernel_vs_oracle_loop(hip, rows, cols, mode, clamp):
