@@ -239,6 +239,95 @@ template <int DT> rows_reg_fn pick_rows_reg_nv(uint32_t per_lane, int fmt, int r
                        : pick_rows_reg<DT, kRegVecs>(fmt, rm);
 }
 
+// Blocks shorter than one 16-byte vector (the emulators' block_size = 1 on embedding tables,
+// hybrid_emu.py:119; 2; 4 for 16-bit storage): one vector per lane as in the flat cast, every element with
+// the scale of its own block.  bs divides V; the buffer is a whole number of vectors.
+template <int FMT, int RM, int DT>
+__global__ __launch_bounds__(kBlock) void rows_subvec_kernel(const void *in_, void *out_, uint64_t nvec,
+                                                             uint32_t bs, float flt_max, int policy,
+                                                             uint64_t seed, uint64_t offset) {
+  constexpr unsigned V = Storage<DT>::V;
+  constexpr bool SR = (RM == STOCHASTIC);
+  const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= nvec) return;
+  const bool bn = (policy == kRowsBlockNorm);
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in_) + idx);
+
+  uint32_t raw[V], a[V];  // storage patterns and their |x| (NaN dropped for block norm)
+#pragma unroll
+  for (unsigned e = 0; e < V; e++) {
+    if constexpr (DT == FPEMU_F32) {
+      raw[e] = v[e];
+      a[e] = (bn ? drop_nan<DT>(raw[e]) : raw[e]) & 0x7FFFFFFFu;
+    } else {
+      raw[e] = (v[e / 2u] >> (16u * (e & 1u))) & 0xFFFFu;
+      a[e] = (bn ? (drop_nan<DT>(raw[e]) & 0xFFFFu) : raw[e]) & 0x7FFFu;
+    }
+  }
+  uint32_t m[V];
+#pragma unroll
+  for (unsigned e = 0; e < V; e++) {
+    uint32_t r = a[e];
+    if (bs >= 2u) r = r > a[e ^ 1u] ? r : a[e ^ 1u];
+    if constexpr (V == 8) {
+      if (bs >= 4u) {
+        const uint32_t p = a[e ^ 2u] > a[e ^ 3u] ? a[e ^ 2u] : a[e ^ 3u];
+        r = r > p ? r : p;
+      }
+    }
+    m[e] = r;
+  }
+  float y[V];
+  Philox4 blk_noise = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (unsigned e = 0; e < V; e++) {
+    uint32_t r = m[e];
+    if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
+    else if constexpr (DT == FPEMU_BF16) r = r << 16;
+    const float scale = bn ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
+    const float rcp = scale_reciprocal(scale);
+    const uint64_t g = idx * V + e;  // global element
+    uint32_t rnd = 0u;
+    if constexpr (SR) {
+      // element c of a block this short is byte c * NB of the block's first Philox draw (rand_bits_elem with
+      // idx = c < V: superblock 0, lane 0, slot 0): one draw per block, not per element
+      constexpr unsigned NB = noise_bytes<FMT>();
+      const unsigned c = e & (bs - 1u);
+      if (c == 0u) blk_noise = philox4x32_10(seed, 0u, offset + g / bs);  // e, bs uniform: scalar branch
+      const unsigned pos = c * NB;
+      rnd = (philox_word(blk_noise, pos / 4u) >> ((pos % 4u) * 8u)) & (NB == 2 ? 0xFFFFu : 0xFFu);
+    }
+    float x;
+    if constexpr (DT == FPEMU_F32) x = u2f(raw[e]);
+    else x = load_elem16<DT>(raw[e]);
+    y[e] = cast_one<FMT, RM>(x, scale, rcp, rnd);
+  }
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if constexpr (DT == FPEMU_F32) o[j] = f2u(y[j]);
+    else o[j] = pack_pair16<DT>(y[2 * j], y[2 * j + 1]);
+  }
+  store_stream(reinterpret_cast<u32x4 *>(out_) + idx, o);
+}
+
+typedef void (*rows_subvec_fn)(const void *, void *, uint64_t, uint32_t, float, int, uint64_t, uint64_t);
+
+template <int DT> rows_subvec_fn pick_rows_subvec(int fmt, int rm) {
+#define FPEMU_CASE(F, R) \
+  if (fmt == F && rm == R) return rows_subvec_kernel<F, R, DT>;
+  FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
+  FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
+  FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
+  FPEMU_CASE(E5M2_DAZ, RNTZ)
+  FPEMU_CASE(E4M3, RTZ) FPEMU_CASE(E4M3, RNE) FPEMU_CASE(E4M3, STOCHASTIC)
+  FPEMU_CASE(E3M4, RTZ) FPEMU_CASE(E3M4, RNE) FPEMU_CASE(E3M4, STOCHASTIC)
+  FPEMU_CASE(E4M3_IEEE, RNE) FPEMU_CASE(E4M3_IEEE, STOCHASTIC)
+  FPEMU_CASE(FP4, RNE)
+#undef FPEMU_CASE
+  return nullptr;
+}
+
 typedef void (*rows_fn)(const void *, void *, uint64_t, uint64_t, float, int, uint64_t, uint64_t, uint32_t *);
 
 template <int DT, bool VEC, int TEAM> rows_fn pick_rows(int fmt, int rm) {
@@ -270,8 +359,30 @@ template <int DT> rows_fn pick_rows_dt(bool vec, int team, int fmt, int rm) {
 extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype,
                                   int fmt, int rmode, float flt_max, int policy, uint64_t seed,
                                   uint64_t offset, uint32_t *amax_out, int force_block, void *stream) {
-  // register-resident path: aligned rows of at most kBlock * kRegVecs vectors
   const unsigned ve = vec_elems(dtype);
+  // blocks shorter than a vector: the flat cast's geometry with a scale per element
+  if (cols < ve && (ve % cols) == 0 && amax_out == nullptr && (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 &&
+      ((rows * cols) % ve) == 0) {
+    rows_subvec_fn sf = dtype == FPEMU_F32 ? pick_rows_subvec<FPEMU_F32>(fmt, rmode)
+                      : dtype == FPEMU_F16 ? pick_rows_subvec<FPEMU_F16>(fmt, rmode)
+                      : dtype == FPEMU_BF16 ? pick_rows_subvec<FPEMU_BF16>(fmt, rmode) : nullptr;
+    if (sf == nullptr) return -100;  // kNoRowsKernel of fpemu_hip.hip
+    const uint64_t nvec = rows * cols / ve;
+    const uint64_t nblk = (nvec + kBlock - 1) / kBlock;
+    if (nblk > 0x7FFFFFFFull) {
+      fpemu_set_error_("fpemu rows: more than 2^31-1 workgroups");
+      return FPEMU_EINVAL;
+    }
+    hipLaunchKernelGGL(sf, dim3((unsigned)nblk), dim3(kBlock), 0, (hipStream_t)stream, in, out, nvec, (uint32_t)cols,
+                       flt_max, policy, seed, offset);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      fpemu_set_error_(hipGetErrorString(e));
+      return (int)e;
+    }
+    return FPEMU_OK;
+  }
+  // register-resident path: aligned rows of at most kBlock * kRegVecs vectors
   if ((((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % ve) == 0 && cols / ve <= (uint64_t)kBlock * kRegVecs) {
     const uint32_t nv = (uint32_t)(cols / ve);
     // lane group: the smallest power of two covering the row's vectors, up to a wave; longer rows keep the
