@@ -35,7 +35,8 @@ namespace {
 
 constexpr int kDefaultMaxBlocks = 0x7FFFFFFF;  // cast: one superblock per wave, no loop
 constexpr int kAmaxMaxBlocks = 256 * 16;       // amax: looped, one atomic per block
-constexpr uint64_t kSmallTensor = 32768;       // <= this many elements: fused one-workgroup path
+constexpr uint64_t kSmallVectors = 2048;       // <= this many 16-byte vectors: fused one-workgroup path (the
+                                               // workgroup holds them in registers: fpemu_rows.hip, rows_reg_kernel)
 constexpr uint64_t kKeepBytes = 160ull << 20;  // fused amax -> cast: tensors up to this size keep cache residency
 constexpr uint64_t kMaxPartials = 256;  // one per CU; measured best of 128 / 256 / 512 / 1024 / 2048
 constexpr int kNoRowsKernel = -100;            // fpemu_rows_launch_: no kernel for this fmt/rmode/dtype
@@ -75,43 +76,24 @@ __device__ __forceinline__ uint32_t lane_noise(const Philox4 (&p)[NCALLS], unsig
 // a second independent vector per lane hides it)
 constexpr int slots_per_wave(int rm, int dt) { return rm == STOCHASTIC ? 4 : (dt == FPEMU_F32 ? 1 : 2); }
 
+// The streaming body: workgroup `blk` of `nblk` that share one buffer (cast_kernel: the whole grid;
+// cast_multi_kernel: the tensor's share of the grid).
 template <int FMT, int RM, int DT>
-__global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out_,
-                                                      uint64_t nsb, uint64_t n, CastParams prm) {
+__device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_t nsb, uint64_t n, float scale,
+                                            float rcp, uint64_t seed, uint64_t offset, uint64_t elem_base,
+                                            unsigned blk, unsigned nblk) {
   constexpr unsigned V = Storage<DT>::V;
   constexpr int U = slots_per_wave(RM, DT);
   constexpr uint64_t SB_ELEMS = (uint64_t)V * 64u * U;
   constexpr bool SR = (RM == STOCHASTIC);
   constexpr int NCALLS = SR ? (int)(4u * V * noise_bytes<FMT>() / 16u) : 1;
 
-  float scale = prm.scale, rcp = prm.rcp;
-  if (prm.npart != 0u) {  // uniform over the launch
-    __shared__ uint32_t pmax[kWavesPerBlock];
-    uint32_t m = 0u;
-    for (uint32_t i = threadIdx.x; i < prm.npart; i += kBlock) {
-      const uint32_t v = prm.partials[i];
-      m = m > v ? m : v;
-    }
-    m = wave_max_u32(m);
-    if ((threadIdx.x & 63u) == 0u) pmax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    uint32_t r = pmax[0];
-#pragma unroll
-    for (int w = 1; w < kWavesPerBlock; w++) r = r > pmax[w] ? r : pmax[w];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *prm.amax_pub = r;
-    scale = scale_from_amax(r, prm.flt_max, prm.clamp != 0);
-    rcp = scale_reciprocal(scale);
-  } else if (prm.amax_bits != nullptr) {
-    scale = scale_from_amax(*prm.amax_bits, prm.flt_max, prm.clamp != 0);
-    rcp = scale_reciprocal(scale);
-  }
-
   const unsigned lane = threadIdx.x & 63u;
-  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  const uint64_t wave = (uint64_t)blk * kWavesPerBlock + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)nblk * kWavesPerBlock;
   const u32x4 *in = reinterpret_cast<const u32x4 *>(in_);
   u32x4 *out = reinterpret_cast<u32x4 *>(out_);
-  const uint64_t sb_base = prm.elem_base / SB_ELEMS;
+  const uint64_t sb_base = elem_base / SB_ELEMS;
 
   for (uint64_t sb = wave; sb < nsb; sb += nwaves) {
     const uint64_t v0 = sb * (64u * U) + lane;
@@ -123,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out
     if constexpr (SR) {
       const uint64_t c = ((sb_base + sb) * 64u + lane) << 2;
 #pragma unroll
-      for (int k = 0; k < NCALLS; k++) p[k] = philox4x32_10(prm.seed, c | (uint64_t)k, prm.offset);
+      for (int k = 0; k < NCALLS; k++) p[k] = philox4x32_10(seed, c | (uint64_t)k, offset);
     }
 
 #pragma unroll
@@ -152,16 +134,71 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out
   using elem_t = typename Storage<DT>::elem;
   const elem_t *ein = reinterpret_cast<const elem_t *>(in_);
   elem_t *eout = reinterpret_cast<elem_t *>(out_);
-  const uint64_t tstride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = nsb * SB_ELEMS + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += tstride) {
+  const uint64_t tstride = (uint64_t)nblk * kBlock;
+  for (uint64_t i = nsb * SB_ELEMS + (uint64_t)blk * kBlock + threadIdx.x; i < n; i += tstride) {
     uint32_t rnd = 0u;
-    if constexpr (SR) rnd = rand_bits_elem<FMT, V>(prm.seed, prm.offset, prm.elem_base + i);
+    if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, offset, elem_base + i);
     if constexpr (DT == FPEMU_F32) {
       eout[i] = cast_one<FMT, RM>(ein[i], scale, rcp, rnd);
     } else {
       eout[i] = (elem_t)store_elem16<DT>(cast_one<FMT, RM>(load_elem16<DT>(ein[i]), scale, rcp, rnd));
     }
   }
+}
+
+template <int FMT, int RM, int DT>
+__global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out_,
+                                                      uint64_t nsb, uint64_t n, CastParams prm) {
+  float scale = prm.scale, rcp = prm.rcp;
+  if (prm.npart != 0u) {  // uniform over the launch
+    __shared__ uint32_t pmax[kWavesPerBlock];
+    uint32_t m = 0u;
+    for (uint32_t i = threadIdx.x; i < prm.npart; i += kBlock) {
+      const uint32_t v = prm.partials[i];
+      m = m > v ? m : v;
+    }
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63u) == 0u) pmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    uint32_t r = pmax[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; w++) r = r > pmax[w] ? r : pmax[w];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *prm.amax_pub = r;
+    scale = scale_from_amax(r, prm.flt_max, prm.clamp != 0);
+    rcp = scale_reciprocal(scale);
+  } else if (prm.amax_bits != nullptr) {
+    scale = scale_from_amax(*prm.amax_bits, prm.flt_max, prm.clamp != 0);
+    rcp = scale_reciprocal(scale);
+  }
+
+  cast_blocks<FMT, RM, DT>(in_, out_, nsb, n, scale, rcp, prm.seed, prm.offset, prm.elem_base, blockIdx.x,
+                           gridDim.x);
+}
+
+// Multi-tensor cast: one launch for up to kMultiTensors buffers of the same storage type and mode (the
+// emulators re-quantise every master parameter after the optimizer step -- emulator_base.py
+// update_fp16_master_params: 161 launches per ResNet-50 step, most of them a few microseconds of
+// latency).  Tensor i is cast exactly as fpemu_cast(in_i, out_i, n_i, ..., seed, offset + i, 0): the
+// same bits as the loop of calls it replaces.  The table travels in the kernel arguments; a workgroup
+// finds its tensor by a scalar scan over the workgroup prefix sums.
+constexpr int kMultiTensors = 32;
+struct MultiTable {
+  const void *in[kMultiTensors];
+  void *out[kMultiTensors];
+  uint64_t n[kMultiTensors];
+  uint64_t nsb[kMultiTensors];        // whole superblocks on the 16-byte path (0: unaligned buffer)
+  uint32_t blk_end[kMultiTensors];    // exclusive prefix end of the tensor's workgroups
+  uint32_t count;
+};
+
+template <int FMT, int RM, int DT>
+__global__ __launch_bounds__(kBlock) void cast_multi_kernel(MultiTable tab, float scale, float rcp, uint64_t seed,
+                                                            uint64_t offset) {
+  unsigned t = 0;
+  while (t + 1u < tab.count && blockIdx.x >= tab.blk_end[t]) t++;  // uniform: scalar loads and compares
+  const unsigned first = t == 0u ? 0u : tab.blk_end[t - 1u];
+  cast_blocks<FMT, RM, DT>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], scale, rcp, seed, offset + t, 0,
+                           blockIdx.x - first, tab.blk_end[t] - first);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -252,6 +289,26 @@ typedef void (*cast_fn)(const void *, void *, uint64_t, uint64_t, CastParams);
 template <int DT> cast_fn pick_cast(int fmt, int rm) {
 #define FPEMU_CASE(F, R) \
   if (fmt == F && rm == R) return cast_kernel<F, R, DT>;
+  FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
+  FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
+  FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
+  FPEMU_CASE(E5M2_DAZ, RNTZ)
+  FPEMU_CASE(E4M3, RTZ) FPEMU_CASE(E4M3, RNE) FPEMU_CASE(E4M3, STOCHASTIC)
+  FPEMU_CASE(E3M4, RTZ) FPEMU_CASE(E3M4, RNE) FPEMU_CASE(E3M4, STOCHASTIC)
+  FPEMU_CASE(BF16, RTZ) FPEMU_CASE(BF16, RNE) FPEMU_CASE(BF16, STOCHASTIC)
+  FPEMU_CASE(FP16, RNE) FPEMU_CASE(FP16, STOCHASTIC)
+  FPEMU_CASE(FP16_DAZ, RNE)
+  FPEMU_CASE(E4M3_IEEE, RNE) FPEMU_CASE(E4M3_IEEE, STOCHASTIC)
+  FPEMU_CASE(FP4, RNE)
+#undef FPEMU_CASE
+  return nullptr;
+}
+
+typedef void (*cast_multi_fn)(MultiTable, float, float, uint64_t, uint64_t);
+
+template <int DT> cast_multi_fn pick_cast_multi(int fmt, int rm) {
+#define FPEMU_CASE(F, R) \
+  if (fmt == F && rm == R) return cast_multi_kernel<F, R, DT>;
   FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
   FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
   FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
@@ -382,6 +439,63 @@ int fpemu_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rm
   return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
 }
 
+int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, int fmt, int rmode, float scale,
+                     uint64_t seed, uint64_t offset, void *stream) {
+  if (count == 0) return FPEMU_OK;
+  if (tensors == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast_multi: null tensor table");
+  if (scale > 3.402823466e+38f) return fail(FPEMU_EINVAL, "fpemu_cast_multi: invalid scale factor (inf)");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_cast_multi: bad dtype id");
+  const cast_multi_fn fn = dtype == FPEMU_F32   ? pick_cast_multi<FPEMU_F32>(fmt, rmode)
+                           : dtype == FPEMU_F16 ? pick_cast_multi<FPEMU_F16>(fmt, rmode)
+                                                : pick_cast_multi<FPEMU_BF16>(fmt, rmode);
+  if (fn == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast_multi: format / rounding-mode pair not defined");
+  const unsigned es = elem_size(dtype);
+  for (uint64_t i = 0; i < count; i++) {  // validate everything before the first launch
+    if (tensors[i].n != 0 && (tensors[i].in == nullptr || tensors[i].out == nullptr))
+      return fail(FPEMU_EINVAL, "fpemu_cast_multi: null buffer");
+    if (((uintptr_t)tensors[i].in % es) || ((uintptr_t)tensors[i].out % es))
+      return fail(FPEMU_EALIGN, "fpemu_cast_multi: buffer not aligned to its element size");
+  }
+  const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 64u * (unsigned)slots_per_wave(rmode, dtype);
+  const float rcp = (float)(1.0 / (double)scale);  // cpp:714
+  uint64_t i = 0;
+  while (i < count) {
+    MultiTable tab;
+    memset(&tab, 0, sizeof(tab));
+    uint64_t blocks = 0;
+    unsigned k = 0;
+    const uint64_t first = i;
+    for (; i < count && k < (unsigned)kMultiTensors; i++, k++) {
+      const fpemu_tensor_t &t = tensors[i];
+      const bool vec_ok = (((uintptr_t)t.in | (uintptr_t)t.out) % 16u) == 0;
+      const uint64_t nsb = vec_ok ? t.n / sb_elems : 0;
+      const uint64_t tail = t.n - nsb * sb_elems;
+      uint64_t b = (nsb + kWavesPerBlock - 1) / kWavesPerBlock;
+      const uint64_t tb = (tail + kBlock - 1) / kBlock;
+      if (b < tb) b = tb;
+      if (b > (uint64_t)max_blocks()) b = (uint64_t)max_blocks();
+      if (blocks + b > 0x7FFFFFFFull) {
+        if (k == 0) return fail(FPEMU_EINVAL, "fpemu_cast_multi: tensor too large for one launch; use fpemu_cast");
+        break;  // this tensor starts the next launch
+      }
+      blocks += b;  // an empty tensor owns no workgroups (and still consumes its offset)
+      tab.in[k] = t.in;
+      tab.out[k] = t.out;
+      tab.n[k] = t.n;
+      tab.nsb[k] = nsb;
+      tab.blk_end[k] = (uint32_t)blocks;
+    }
+    tab.count = k;
+    if (blocks != 0) {
+      hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, tab, scale, rcp, seed,
+                         offset + first);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+  }
+  return FPEMU_OK;
+}
+
 int fpemu_forward(const void *in, void *out, int dtype, const char *mode, uint64_t size, float scale,
                   int block_norm, int block_size, uint64_t seed, uint64_t offset, void *stream) {
   int fmt = 0, rmode = 0;
@@ -456,9 +570,10 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
   if (amax_ws == nullptr) return fail(FPEMU_EINVAL, "fpemu_quantize_per_tensor: null workspace");
   if (n == 0) return FPEMU_OK;
   // Small tensors (the per-layer casts of configs 3/4): ONE launch -- a single workgroup reduces,
-  // publishes the amax word and casts (the rows kernel with one row).  Stochastic noise of row 0
+  // publishes the amax word and casts (the rows kernel with one row).  Larger ones are latency-bound in one
+  // workgroup (17 us at 32 Ki elements, measured in a ResNet-50 step) and take the multi-launch paths.  Stochastic noise of row 0
   // at `offset` is exactly the flat layout's, so results do not depend on which path ran.
-  if (n <= kSmallTensor && in != nullptr && out != nullptr && dtype >= FPEMU_F32 && dtype <= FPEMU_BF16 &&
+  if (dtype >= FPEMU_F32 && dtype <= FPEMU_BF16 && n <= kSmallVectors * vec_elems(dtype) && in != nullptr && out != nullptr &&
       ((uintptr_t)in % elem_size(dtype)) == 0 && ((uintptr_t)out % elem_size(dtype)) == 0) {
     const int rc1 = fpemu_rows_launch_(in, out, 1, n, dtype, fmt, rmode, flt_max, clamp ? 1 : 0, seed, offset,
                                        amax_ws, /*force_block=*/1, stream);
@@ -483,7 +598,7 @@ int fpemu_quantize_per_tensor_ws(const void *in, void *out, uint64_t n, int dtyp
                        ((uintptr_t)in % elem_size(dtype)) == 0 && ((uintptr_t)out % elem_size(dtype)) == 0;
   // above the one-workgroup size: two launches -- per-block maxima into ws[1..], then the cast, whose
   // blocks each reduce those maxima (L2 hits) -- instead of zero + atomic amax + cast
-  if (args_ok && n > kSmallTensor && ws_words >= 2 &&
+  if (args_ok && n > kSmallVectors * vec_elems(dtype) && ws_words >= 2 &&
       pick_cast_dt(dtype, fmt, rmode) != nullptr && fmt != BF16 && fmt != FP16 && fmt != FP16_DAZ) {
     const bool vec_ok = ((uintptr_t)in % 16u) == 0;
     const uint64_t nvec = vec_ok ? n / vec_elems(dtype) : 0;

@@ -115,23 +115,53 @@ class EmulatorBase(object):
             return list(amp.master_params(optimizer))
         return [p for g in optimizer.param_groups for p in g["params"]]
 
+    @staticmethod
+    def _cast_run(params, mode):
+        """`param.data = FPEmuOp.apply(param.data, mode, True)` for every parameter of the run, batched: runs of
+        parameters that share a dtype and device go through the multi-tensor cast (same bits, same call
+        offsets as the loop; 32 tensors per launch instead of one)."""
+        from .pytquant import fpemu_cuda
+        from .pytquant.hip import _binding as hip
+        fmt, rmode = hip.parse_mode(mode)
+        i = 0
+        while i < len(params):
+            j = i + 1
+            head = params[i].data
+            while j < len(params) and params[j].data.dtype == head.dtype and params[j].data.device == head.device:
+                j += 1
+            run = [p.data for p in params[i:j]]
+            if j - i > 1 and head.is_cuda and all(t.is_contiguous() for t in run):
+                hip.cast_multi_(run, fmt, rmode)
+            else:
+                for p in params[i:j]:
+                    p.data = fpemu_cuda.FPEmuOp.apply(p.data, mode, True)
+            i = j
+
     def update_fp16_master_params(self, optimizer):
         """FLOAT16_STOCHASTIC on every master parameter, plus the embedding format on parameters
-        whose name contains "embeddings" (hybrid_emu.py:110-176)."""
+        whose name contains "embeddings" (hybrid_emu.py:110-176).  Same sequence of casts and call offsets
+        as the reference's loop; the FLOAT16 casts between two embedding parameters are batched."""
         from .pytquant import fpemu_cuda
         names = [n for n, _ in self.model.named_parameters()]
+        pending = []
         for param, name in zip(self._master_params(optimizer), names):
+            if self.emb_master_mode is None or "embeddings" not in name:
+                pending.append(param)
+                continue
+            self._cast_run(pending, "FLOAT16_STOCHASTIC")
+            pending = []
             param.data = fpemu_cuda.FPEmuOp.apply(param.data, "FLOAT16_STOCHASTIC", True)
-            if self.emb_master_mode is not None and "embeddings" in name:
-                if self.emb_norm:
-                    # (1-D "embeddings" parameters such as LayerNorm weights: the reference's
-                    # param.size()[1] raises IndexError; only the value's truth is used, so pass 1)
-                    cols = param.size()[1] if param.dim() > 1 else 1
-                    param.data = fpemu_cuda.FPEmuOp.apply(param.data, self.emb_master_mode, True, self.emb_norm, cols)
-                else:
-                    param.data = fpemu_cuda.FPEmuOp.apply(param.data, self.emb_master_mode, True)
+            if self.emb_norm:
+                # (1-D "embeddings" parameters such as LayerNorm weights: the reference's
+                # param.size()[1] raises IndexError; only the value's truth is used, so pass 1)
+                cols = param.size()[1] if param.dim() > 1 else 1
+                param.data = fpemu_cuda.FPEmuOp.apply(param.data, self.emb_master_mode, True, self.emb_norm, cols)
+            else:
+                param.data = fpemu_cuda.FPEmuOp.apply(param.data, self.emb_master_mode, True)
+        self._cast_run(pending, "FLOAT16_STOCHASTIC")
 
     def update_e5m2_master_params(self, optimizer):
+        """FLOAT16_STOCHASTIC then E5M2_STOCHASTIC on every master parameter (hybrid_emu.py:178-190)."""
         from .pytquant import fpemu_cuda
         for param in self._master_params(optimizer):
             param.data = fpemu_cuda.FPEmuOp.apply(param.data, "FLOAT16_STOCHASTIC", True)

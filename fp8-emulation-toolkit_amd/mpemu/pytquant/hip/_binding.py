@@ -79,7 +79,9 @@ def lib():
         L.fpemu_set_max_blocks.argtypes = [i32]
         L.fpemu_quantize_blocks.restype = i32
         L.fpemu_quantize_blocks.argtypes = [vp, vp, u64, u64, i32, i32, i32, u64, u64, vp]
-        if L.fpemu_abi_version() != 4:
+        L.fpemu_cast_multi.restype = i32
+        L.fpemu_cast_multi.argtypes = [vp, u64, i32, i32, i32, f32, u64, u64, vp]
+        if L.fpemu_abi_version() != 5:
             raise ImportError("libfpemu_hip.so: ABI version mismatch")
         _lib = L
     return _lib
@@ -209,6 +211,42 @@ def cast_(src, dst, fmt, rmode, scale=1.0, seed=None, offset=None, elem_base=0):
                                 float(scale), _seed if seed is None else seed, offset, elem_base,
                                 _stream(src)))
     return dst
+
+
+class _TensorEntry(ctypes.Structure):  # fpemu_tensor_t
+    _fields_ = [("inp", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_uint64)]
+
+
+def cast_multi_(srcs, fmt, rmode, scale=1.0, dsts=None, seed=None, offset=None):
+    """Cast a list of contiguous tensors of one dtype on one device (in place unless `dsts` is given) in
+    as few launches as possible.  Tensor i gets call offset `offset + i`: the same bits as a loop of
+    cast_() calls, and the call counter advances by len(srcs) exactly as that loop would."""
+    global _offset
+    srcs = list(srcs)
+    dsts = srcs if dsts is None else list(dsts)
+    if len(dsts) != len(srcs):
+        raise ValueError("fpemu: input/output lists differ in length")
+    if not srcs:
+        return dsts
+    first = srcs[0]
+    tab = (_TensorEntry * len(srcs))()
+    for i, (a, b) in enumerate(zip(srcs, dsts)):
+        _require_device(a)
+        _require_device(b, "output")
+        if a.dtype != first.dtype or a.device != first.device or b.dtype != a.dtype or b.device != a.device:
+            raise ValueError("fpemu: cast_multi_ needs tensors of one dtype on one device")
+        if b.numel() != a.numel():
+            raise ValueError("fpemu: input/output mismatch")
+        tab[i].inp, tab[i].out, tab[i].n = a.data_ptr(), b.data_ptr(), a.numel()
+    if offset is None:
+        offset = 0
+        if rmode == STOCHASTIC:
+            offset = _offset
+            _offset += len(srcs)
+    with _range("fpemu::cast_multi"), _on_device(first):
+        _check(lib().fpemu_cast_multi(ctypes.cast(tab, ctypes.c_void_p), len(srcs), _dtype_id(first), fmt, rmode,
+                                      float(scale), _seed if seed is None else seed, offset, _stream(first)))
+    return dsts
 
 
 def amax_(src, amax_bits):

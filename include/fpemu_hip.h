@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FPEMU_ABI_VERSION 4
+#define FPEMU_ABI_VERSION 5
 
 /* Storage dtype of in/out buffers. */
 enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
@@ -94,6 +94,20 @@ int fpemu_parse_mode(const char *mode, int *fmt, int *rmode);
  * 64-bit n: the reference's `int size` overflows at 2^31 elements. */
 int fpemu_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode, float scale,
                uint64_t seed, uint64_t offset, uint64_t elem_base, void *stream);
+
+/* The same cast over a list of buffers in as few launches as possible (32 buffers per launch): tensor i
+ * is cast exactly as fpemu_cast(in_i, out_i, n_i, dtype, fmt, rmode, scale, seed, offset + i, 0, stream),
+ * bit for bit -- what a loop of calls with a counter that advances by one per call produces.  Replaces
+ * the reference's per-parameter loops of FPEmuOp calls after the optimizer step
+ * (mpemu/emulator_base.py:update_fp16_master_params / update_e5m2_master_params; one cast launch + one
+ * hipDeviceSynchronize per parameter there).  `tensors` is host memory, read before the call returns. */
+typedef struct fpemu_tensor {
+  const void *in;
+  void *out;
+  uint64_t n;
+} fpemu_tensor_t;
+int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, int fmt, int rmode, float scale,
+                     uint64_t seed, uint64_t offset, void *stream);
 
 /* Mirror of the pybind `forward` signature (hip/fpemu_impl.cpp:27-37): mode string, size,
  * scale, block_norm, block_size.  inplace <=> out == in.  block_norm: as the reference

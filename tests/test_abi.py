@@ -69,6 +69,17 @@ def test_argument_errors_without_gpu():
     assert L.fpemu_forward(None, None, 0, b"E4M3_RNE", 16, 1.0, 1, 4, 0, 0, None) == -1  # block_norm: null buffers
     assert b"quantize_blocks" in L.fpemu_last_error()
     assert L.fpemu_amax(None, 4, 0, None, None) == -1
+    tab = (b._TensorEntry * 2)()
+    tab[0].inp, tab[0].out, tab[0].n = 16, 16, 0
+    tab[1].inp, tab[1].out, tab[1].n = None, None, 4
+    tp = ctypes.cast(tab, ctypes.c_void_p)
+    assert L.fpemu_cast_multi(tp, 0, 0, 1, 1, 1.0, 0, 0, None) == 0              # empty list
+    assert L.fpemu_cast_multi(tp, 1, 0, 1, 1, 1.0, 0, 0, None) == 0              # one empty tensor: no launch
+    assert L.fpemu_cast_multi(tp, 2, 0, 1, 1, 1.0, 0, 0, None) == -1             # null buffer with n > 0
+    assert L.fpemu_cast_multi(None, 2, 0, 1, 1, 1.0, 0, 0, None) == -1
+    assert L.fpemu_cast_multi(tp, 1, 0, 1, 5, 1.0, 0, 0, None) == -1             # undefined mode pair
+    tab[1].inp, tab[1].out = 18, 18
+    assert L.fpemu_cast_multi(tp, 2, 0, 1, 1, 1.0, 0, 0, None) == -4             # misaligned fp32
     assert L.fpemu_amax(16, 0, 0, 16, None) == 0
     assert L.fpemu_cast_scaled(16, 16, 4, 0, 1, 1, None, 448.0, 1, 0, 0, 0, None) == -1
     assert L.fpemu_quantize_per_tensor(16, 16, 4, 0, 1, 1, 448.0, 1, None, 0, 0, None) == -1

@@ -174,6 +174,49 @@ def test_direct_e5m2_training_and_module_lists():
     net(x).sum().backward()
 
 
+def test_master_param_update_equals_the_reference_loop():
+    """update_fp16_master_params batches the FLOAT16_STOCHASTIC casts between embedding parameters into
+    multi-tensor launches: same bits and same call counter as the reference's per-parameter loop
+    (hybrid_emu.py:110-134)."""
+    from mpemu import mpt_emu
+    from mpemu.pytquant import fpemu_cuda
+    from mpemu.pytquant.hip import _binding as hip
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(40, 70)
+            self.embeddings = torch.nn.Embedding(50, 16)
+            self.b = torch.nn.Linear(70, 33)
+            self.c = torch.nn.Conv2d(3, 8, 3)
+            self.norm = torch.nn.LayerNorm(33)
+
+    torch.manual_seed(2)
+    model = Net().to(DEV)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    model, emu = mpt_emu.initialize(model, opt, training_algo="hybrid", device="cuda")
+    emu.set_master_param_precision("fp16")
+    emu.set_embedding_precision("e4m3", emb_norm=True)
+    before = [p.detach().clone() for p in model.parameters()]
+    names = [n for n, _ in model.named_parameters()]
+
+    hip.set_rng_state((3, 40))
+    want = []
+    for t, name in zip(before, names):       # the reference's loop, one call per cast
+        t = fpemu_cuda.FPEmuOp.apply(t.clone(), "FLOAT16_STOCHASTIC", True)
+        if "embeddings" in name:
+            t = fpemu_cuda.FPEmuOp.apply(t, "E4M3_STOCHASTIC", True, True, t.size()[1])
+        want.append(t)
+    state = hip.get_rng_state()
+
+    hip.set_rng_state((3, 40))
+    emu.emulator.update_master_params(opt)
+    assert hip.get_rng_state() == state
+    for p, w, name in zip(model.parameters(), want, names):
+        assert torch.equal(p.detach().view(torch.int32), w.view(torch.int32)), name
+        assert _is_fixed_point(p, "FLOAT16_RNE"), name
+
+
 def test_bert_base_ptq_e4m3():
     """BASELINE config 3, synthetic: random-init BERT-base, E4M3 PTQ with per-channel weights and
     per-tensor input activations through the module hooks."""

@@ -405,3 +405,47 @@ def test_per_tensor_workspace_path_equals_single_word_path(hip, n, mode):
         o3 = torch.empty(n, device=DEV)
         hip.quantize_per_tensor_(t, o3, fmt, rm, fmax)                          # cached per-stream scratch
         assert torch.equal(o1.view(torch.int32), o3.view(torch.int32))
+
+
+# ------------------------------------------------------------------------------------------
+# multi-tensor cast: one launch for a list of buffers == the loop of single casts
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["FLOAT16_STOCHASTIC", "E4M3_RNE", "E5M2_STOCHASTIC", "BFLOAT16_RNE"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_cast_multi_equals_loop_of_casts(hip, mode, dt):
+    fmt, rm = hip.parse_mode(mode)
+    sizes = [1, 0, 7, 64, 1000, 4096, 65536 + 3, 3 * 7 * 7 * 64, 1 << 20, 5, 0, 2048] + [33 + 17 * i for i in range(60)]
+    g = torch.Generator(device=DEV).manual_seed(5)
+    base = [(torch.randn(n + 3, device=DEV, generator=g) * 4).to(dt) for n in sizes]
+    # every third tensor is a view that is not 16-byte aligned (element path inside the same launch)
+    srcs = [b[1:1 + n] if i % 3 == 2 else b[:n] for i, (b, n) in enumerate(zip(base, sizes))]
+    want = []
+    hip.set_rng_state((11, 500))
+    for t in srcs:
+        want.append(hip.cast_(t, torch.empty_like(t), fmt, rm, scale=1.0))
+    state_after_loop = hip.get_rng_state()
+    hip.set_rng_state((11, 500))
+    outs = [torch.empty_like(t) for t in srcs]
+    hip.cast_multi_(srcs, fmt, rm, dsts=outs)
+    assert hip.get_rng_state() == state_after_loop
+    for i, (a, b) in enumerate(zip(outs, want)):
+        assert torch.equal(a.view(torch.int16 if dt != torch.float32 else torch.int32),
+                           b.view(torch.int16 if dt != torch.float32 else torch.int32)), (mode, dt, i, sizes[i])
+    # in place, and against the oracle for one deterministic case
+    clones = [t.clone() for t in srcs]
+    hip.set_rng_state((11, 500))
+    hip.cast_multi_(clones, fmt, rm)
+    for i, (a, b) in enumerate(zip(clones, want)):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (mode, dt, i)
+    if mode == "E4M3_RNE" and dt == torch.float32:
+        assert_bits_equal(outs[8].cpu().numpy(), orc.cast(srcs[8].cpu().numpy(), mode), "multi vs oracle")
+
+
+def test_cast_multi_rejects_mixed_lists(hip):
+    a = torch.randn(8, device=DEV)
+    with pytest.raises(ValueError):
+        hip.cast_multi_([a, a.half()], *hip.parse_mode("E4M3_RNE"))
+    with pytest.raises(ValueError):
+        hip.cast_multi_([a], *hip.parse_mode("E4M3_RNE"), dsts=[torch.empty(9, device=DEV)])
+    with pytest.raises(RuntimeError):
+        hip.cast_multi_([a, torch.randn(8)], *hip.parse_mode("E4M3_RNE"))
