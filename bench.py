@@ -10,8 +10,10 @@ casts shard with no collective.  Rank 0 prints ONE JSON line.
 
 Extra (untimed for `value`) sections in the same line: per-mode rates for every format x
 rounding mode, the per-tensor-scaled path (amax + all-reduce(max) over RCCL when N > 1 + cast),
-the `roofline` of the dominant kernel from HIP events, and `cpu_baseline`: the CPU oracle
-(port of the reference algorithm, OpenMP) timed on this box's host cores on the same data.
+the `roofline` of the dominant kernel from HIP events over the timed region, and `cpu_baseline`: the
+reference's own fpemu_cpp (oracle/_ref, prebuilt from /root/reference; kind "reference") timed on this box's
+host cores on a sample of the same data, with the C restatement (kind "port", OpenMP) beside it -- the port
+alone where the prebuilt extension is absent or does not run on this host.
 """
 import argparse
 import json
@@ -60,6 +62,41 @@ def time_launches(fn, steps):
     return sum(per) / len(per), min(per)
 
 
+def reference_baseline(sample, mode, gpu_head):
+    """The reference's own fpemu_cpp (oracle/_ref/native, built from /root/reference in the build container)
+    timed on this host in a child process; None when the prebuilt extension is absent or does not run here."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+
+    so = os.path.join(ROOT, "oracle", "_ref", "native", "fpemu_ref_native.so")
+    if not os.path.isfile(so):
+        return None
+    with tempfile.TemporaryDirectory(prefix="fpemu_bench_") as tmp:
+        src, dst = os.path.join(tmp, "in.npy"), os.path.join(tmp, "head.npy")
+        np.save(src, sample)
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_time.py"), src, dst, mode, "12"],
+                               capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return None
+            res = json.loads(r.stdout.strip().splitlines()[-1])
+            head = np.load(dst).view(np.uint32)
+        except Exception:
+            return None
+    oop, inp = res["out_of_place"], res["in_place"]
+    return {"value": round(oop["elements_per_s"], 1), "unit": "elements/s",
+            "cores": 1 if mode.startswith(("E4M3", "E3M4")) else res["torch_threads"], "kind": "reference",
+            "sample": "%s over the first %d elements of the same tensor through the reference's fpemu_cpp.forward, "
+                      "out-of-place as its FPEmuOp calls it (zeros_like + cast): %d passes in %.2f s; its E4M3/E3M4 "
+                      "AVX-512 routine runs on one thread (no OpenMP pragma, cpp/fpemu_impl.cpp:934), torch threads "
+                      "for the allocation: %d" % (mode, res["elements"], oop["passes"], oop["seconds"],
+                                                  res["torch_threads"]),
+            "in_place_value": round(inp["elements_per_s"], 1),
+            "gpu_matches_reference_on_first_4Mi": bool(np.array_equal(gpu_head, head[: gpu_head.size]))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,9 +141,15 @@ def main():
         step()
     barrier()
     torch.cuda.synchronize()
+    # The timed region: EXACTLY `steps` launches.  One HIP event after each launch, recorded on the stream
+    # the kernels run on (torch's current stream, which the binding passes to the C ABI): the wall clock gives
+    # `value`, the events give the dominant kernel's launch duration over the same launches (`roofline`).
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
         step()
+        ev[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -117,8 +160,9 @@ def main():
         ms = float(t.item())
     value = world * n / (ms * 1e-3)
 
-    # roofline of the dominant kernel: HIP events around each launch on the launch stream
-    avg_ms, min_ms = time_launches(step, max(10, min(args.steps, 50)))
+    # roofline of the dominant kernel from the events of the timed region
+    per = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    avg_ms, min_ms = sum(per) / len(per), min(per)
     achieved = BYTES_PER_ELEM * n / (avg_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -130,7 +174,8 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "cast_kernel<E4M3,RNE,f32>", "avg_launch_ms": round(avg_ms, 5),
-                "min_launch_ms": round(min_ms, 5), "algorithmic_bytes_per_launch": BYTES_PER_ELEM * n}
+                "min_launch_ms": round(min_ms, 5), "algorithmic_bytes_per_launch": BYTES_PER_ELEM * n,
+                "timing": "HIP events on the launch stream, one per launch of the timed region"}
 
     extras = {}
     cpu_baseline = None
@@ -254,13 +299,17 @@ def main():
         step()
         torch.cuda.synchronize()
         chk = slice(0, 1 << 22)
-        same = bool(np.array_equal(y[chk].cpu().numpy().view(np.uint32), out[chk].view(np.uint32)))
-        cpu_baseline = {"value": round(sample * passes / cpu_s, 1), "unit": "elements/s",
-                        "cores": orc.num_threads(), "kind": "port",
-                        "sample": "%s over the first %d elements of the same tensor, %d timed passes (%.2f s wall) of "
-                                  "the OpenMP C oracle (oracle/fpemu_oracle.c), output pre-faulted" % (
-                                      args.mode, sample, passes, cpu_s),
-                        "gpu_matches_oracle_on_first_4Mi": same}
+        gpu_head = y[chk].cpu().numpy().view(np.uint32)
+        same = bool(np.array_equal(gpu_head, out[chk].view(np.uint32)))
+        port = {"value": round(sample * passes / cpu_s, 1), "unit": "elements/s",
+                "cores": orc.num_threads(), "kind": "port",
+                "sample": "%s over the first %d elements of the same tensor, %d timed passes (%.2f s wall) of "
+                          "the OpenMP C oracle (oracle/fpemu_oracle.c), output pre-faulted" % (
+                              args.mode, sample, passes, cpu_s),
+                "gpu_matches_oracle_on_first_4Mi": same}
+        cpu_baseline = reference_baseline(hx[: 1 << 26], args.mode, gpu_head) or port
+        if cpu_baseline is not port:
+            cpu_baseline["port"] = port
 
     if rank == 0:
         line = {

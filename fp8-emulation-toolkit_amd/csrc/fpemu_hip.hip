@@ -49,17 +49,23 @@ int fail(int code, const char *msg) {
   return code;
 }
 
+// Everything the cast kernel needs besides the four leading scalars.  The kernel takes the first
+// fields as plain scalar arguments (see cast_kernel): together with in / out / nsb / n they are the 14
+// dwords that gfx950 preloads into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, Makefile),
+// so an unscaled cast issues its global load without waiting for a single scalar load.
 struct CastParams {
   float scale;                // host-provided scale (ignored when amax_bits != nullptr)
   float rcp;                  // (float)(1.0/(double)scale), computed on the host
   const uint32_t *amax_bits;  // device word; non-null: derive scale on device
-  float flt_max;
+  uint32_t npart;             // > 0: `rest.partials` holds per-block maxima of a preceding amax_kernel<.., PARTIAL>
   int clamp;
-  uint64_t seed, offset;
-  uint64_t elem_base;         // global index of element 0 of this buffer
-  const uint32_t *partials;   // npart > 0: per-block maxima of a preceding amax_kernel<.., PARTIAL> launch;
-  uint32_t npart;             //            every block reduces them itself (no atomics, no pre-zeroed word)
-  uint32_t *amax_pub;         //            and block 0 publishes the maximum here
+  struct Rest {               // not preloaded: fetched by scalar loads where a path needs them
+    float flt_max;
+    uint64_t seed, offset;
+    uint64_t elem_base;       // global index of element 0 of this buffer
+    const uint32_t *partials; // npart > 0: every block reduces them itself (no atomics, no pre-zeroed word)
+    uint32_t *amax_pub;       //            and block 0 publishes the maximum here
+  } rest;
 };
 
 // Random bits for element e (0..V-1) of slot s from the lane's Philox results of this superblock.
@@ -76,11 +82,51 @@ __device__ __forceinline__ uint32_t lane_noise(const Philox4 (&p)[NCALLS], unsig
 // a second independent vector per lane hides it)
 constexpr int slots_per_wave(int rm, int dt) { return rm == STOCHASTIC ? 4 : (dt == FPEMU_F32 ? 1 : 2); }
 
+// Scale sources of the streaming body.  resolve() runs once per thread AFTER the first superblock's
+// loads have been issued, so whatever it waits for (a device word, the per-block maxima, a barrier)
+// overlaps the HBM latency of the data instead of preceding it.
+struct GivenScale {
+  float scale, rcp;
+  __device__ __forceinline__ void resolve(float &s, float &r) const { s = scale; r = rcp; }
+};
+
+struct DeviceScale {  // cast_kernel: scale given, or derived from a device word / per-block maxima
+  float scale, rcp;
+  const uint32_t *amax_bits;
+  uint32_t npart;
+  int clamp;
+  const CastParams::Rest *rest;
+  __device__ __forceinline__ void resolve(float &s, float &r) const {
+    s = scale;
+    r = rcp;
+    if (npart != 0u) {  // uniform over the launch
+      __shared__ uint32_t pmax[kWavesPerBlock];
+      uint32_t m = 0u;
+      for (uint32_t i = threadIdx.x; i < npart; i += kBlock) {
+        const uint32_t v = rest->partials[i];
+        m = m > v ? m : v;
+      }
+      m = wave_max_u32(m);
+      if ((threadIdx.x & 63u) == 0u) pmax[threadIdx.x >> 6] = m;
+      __syncthreads();
+      uint32_t mx = pmax[0];
+#pragma unroll
+      for (int w = 1; w < kWavesPerBlock; w++) mx = mx > pmax[w] ? mx : pmax[w];
+      if (blockIdx.x == 0 && threadIdx.x == 0) *rest->amax_pub = mx;
+      s = scale_from_amax(mx, rest->flt_max, clamp != 0);
+      r = scale_reciprocal(s);
+    } else if (amax_bits != nullptr) {
+      s = scale_from_amax(*amax_bits, rest->flt_max, clamp != 0);
+      r = scale_reciprocal(s);
+    }
+  }
+};
+
 // The streaming body: workgroup `blk` of `nblk` that share one buffer (cast_kernel: the whole grid;
 // cast_multi_kernel: the tensor's share of the grid).
-template <int FMT, int RM, int DT>
-__device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_t nsb, uint64_t n, float scale,
-                                            float rcp, uint64_t seed, uint64_t offset, uint64_t elem_base,
+template <int FMT, int RM, int DT, class ScaleSrc>
+__device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_t nsb, uint64_t n,
+                                            const ScaleSrc &src, uint64_t seed, uint64_t offset, uint64_t elem_base,
                                             unsigned blk, unsigned nblk) {
   constexpr unsigned V = Storage<DT>::V;
   constexpr int U = slots_per_wave(RM, DT);
@@ -89,18 +135,26 @@ __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_
   constexpr int NCALLS = SR ? (int)(4u * V * noise_bytes<FMT>() / 16u) : 1;
 
   const unsigned lane = threadIdx.x & 63u;
-  const uint64_t wave = (uint64_t)blk * kWavesPerBlock + (threadIdx.x >> 6);
-  const uint64_t nwaves = (uint64_t)nblk * kWavesPerBlock;
   const u32x4 *in = reinterpret_cast<const u32x4 *>(in_);
   u32x4 *out = reinterpret_cast<u32x4 *>(out_);
-  const uint64_t sb_base = elem_base / SB_ELEMS;
 
-  for (uint64_t sb = wave; sb < nsb; sb += nwaves) {
+  // first (normally the only) superblock of this wave: issue its loads before anything else
+  uint64_t sb = (uint64_t)blk * kWavesPerBlock + (threadIdx.x >> 6);
+  bool have = sb < nsb;
+  u32x4 v[U];
+  if (have) {
     const uint64_t v0 = sb * (64u * U) + lane;
-    u32x4 v[U];
 #pragma unroll
     for (int s = 0; s < U; s++) v[s] = __builtin_nontemporal_load(&in[v0 + (uint64_t)s * 64u]);
+  }
 
+  float scale, rcp;
+  src.resolve(scale, rcp);
+
+  const uint64_t nwaves = (uint64_t)nblk * kWavesPerBlock;
+  const uint64_t sb_base = elem_base / SB_ELEMS;
+  while (have) {
+    const uint64_t v0 = sb * (64u * U) + lane;
     Philox4 p[NCALLS];
     if constexpr (SR) {
       const uint64_t c = ((sb_base + sb) * 64u + lane) << 2;
@@ -127,6 +181,14 @@ __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_
       }
       store_stream(&out[v0 + (uint64_t)s * 64u], o);
     }
+
+    sb += nwaves;  // only grids capped by fpemu_set_max_blocks come round again
+    have = sb < nsb;
+    if (have) {
+      const uint64_t w0 = sb * (64u * U) + lane;
+#pragma unroll
+      for (int s = 0; s < U; s++) v[s] = __builtin_nontemporal_load(&in[w0 + (uint64_t)s * 64u]);
+    }
   }
 
   // Tail (n % superblock) and unaligned buffers (launched with nsb == 0): one element per lane
@@ -146,32 +208,13 @@ __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_
   }
 }
 
+// The first ten arguments are 14 dwords: the part of the kernarg segment gfx950 preloads into SGPRs.
 template <int FMT, int RM, int DT>
-__global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out_,
-                                                      uint64_t nsb, uint64_t n, CastParams prm) {
-  float scale = prm.scale, rcp = prm.rcp;
-  if (prm.npart != 0u) {  // uniform over the launch
-    __shared__ uint32_t pmax[kWavesPerBlock];
-    uint32_t m = 0u;
-    for (uint32_t i = threadIdx.x; i < prm.npart; i += kBlock) {
-      const uint32_t v = prm.partials[i];
-      m = m > v ? m : v;
-    }
-    m = wave_max_u32(m);
-    if ((threadIdx.x & 63u) == 0u) pmax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    uint32_t r = pmax[0];
-#pragma unroll
-    for (int w = 1; w < kWavesPerBlock; w++) r = r > pmax[w] ? r : pmax[w];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *prm.amax_pub = r;
-    scale = scale_from_amax(r, prm.flt_max, prm.clamp != 0);
-    rcp = scale_reciprocal(scale);
-  } else if (prm.amax_bits != nullptr) {
-    scale = scale_from_amax(*prm.amax_bits, prm.flt_max, prm.clamp != 0);
-    rcp = scale_reciprocal(scale);
-  }
-
-  cast_blocks<FMT, RM, DT>(in_, out_, nsb, n, scale, rcp, prm.seed, prm.offset, prm.elem_base, blockIdx.x,
+__global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out_, uint64_t nsb, uint64_t n,
+                                                      float scale, float rcp, const uint32_t *amax_bits,
+                                                      uint32_t npart, int clamp, CastParams::Rest rest) {
+  const DeviceScale src{scale, rcp, amax_bits, npart, clamp, &rest};
+  cast_blocks<FMT, RM, DT>(in_, out_, nsb, n, src, rest.seed, rest.offset, rest.elem_base, blockIdx.x,
                            gridDim.x);
 }
 
@@ -197,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void cast_multi_kernel(MultiTable tab, floa
   unsigned t = 0;
   while (t + 1u < tab.count && blockIdx.x >= tab.blk_end[t]) t++;  // uniform: scalar loads and compares
   const unsigned first = t == 0u ? 0u : tab.blk_end[t - 1u];
-  cast_blocks<FMT, RM, DT>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], scale, rcp, seed, offset + t, 0,
+  cast_blocks<FMT, RM, DT>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], GivenScale{scale, rcp}, seed, offset + t, 0,
                            blockIdx.x - first, tab.blk_end[t] - first);
 }
 
@@ -284,7 +327,8 @@ __global__ void zero_word_kernel(uint32_t *w) { *w = 0u; }
 // ---------------------------------------------------------------------------------------------
 // Host side: dispatch tables and launch geometry.
 // ---------------------------------------------------------------------------------------------
-typedef void (*cast_fn)(const void *, void *, uint64_t, uint64_t, CastParams);
+typedef void (*cast_fn)(const void *, void *, uint64_t, uint64_t, float, float, const uint32_t *, uint32_t, int,
+                        CastParams::Rest);
 
 template <int DT> cast_fn pick_cast(int fmt, int rm) {
 #define FPEMU_CASE(F, R) \
@@ -349,7 +393,7 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
 
   const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 64u * (unsigned)slots_per_wave(rmode, dtype);
   const bool vec_ok = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 &&
-                      (rmode != STOCHASTIC || (prm.elem_base % sb_elems) == 0);
+                      (rmode != STOCHASTIC || (prm.rest.elem_base % sb_elems) == 0);
   const uint64_t nsb = vec_ok ? n / sb_elems : 0;
   const uint64_t tail = n - nsb * sb_elems;
   uint64_t blocks = (nsb + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -359,7 +403,7 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
   if (blocks == 0) blocks = 1;
 
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, in, out, nsb,
-                     n, prm);
+                     n, prm.scale, prm.rcp, prm.amax_bits, prm.npart, prm.clamp, prm.rest);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
   return FPEMU_OK;
@@ -428,14 +472,14 @@ int fpemu_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rm
   prm.scale = scale;
   prm.rcp = (float)(1.0 / (double)scale);  // cpp:714
   prm.amax_bits = nullptr;
-  prm.flt_max = 0.f;
+  prm.rest.flt_max = 0.f;
   prm.clamp = 0;
-  prm.seed = seed;
-  prm.offset = offset;
-  prm.elem_base = elem_base;
-  prm.partials = nullptr;
+  prm.rest.seed = seed;
+  prm.rest.offset = offset;
+  prm.rest.elem_base = elem_base;
+  prm.rest.partials = nullptr;
   prm.npart = 0;
-  prm.amax_pub = nullptr;
+  prm.rest.amax_pub = nullptr;
   return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
 }
 
@@ -553,14 +597,14 @@ int fpemu_cast_scaled(const void *in, void *out, uint64_t n, int dtype, int fmt,
   prm.scale = 1.f;
   prm.rcp = 1.f;
   prm.amax_bits = amax_bits;
-  prm.flt_max = flt_max;
+  prm.rest.flt_max = flt_max;
   prm.clamp = clamp;
-  prm.seed = seed;
-  prm.offset = offset;
-  prm.elem_base = elem_base;
-  prm.partials = nullptr;
+  prm.rest.seed = seed;
+  prm.rest.offset = offset;
+  prm.rest.elem_base = elem_base;
+  prm.rest.partials = nullptr;
   prm.npart = 0;
-  prm.amax_pub = nullptr;
+  prm.rest.amax_pub = nullptr;
   return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
 }
 
@@ -617,14 +661,14 @@ int fpemu_quantize_per_tensor_ws(const void *in, void *out, uint64_t n, int dtyp
     prm.scale = 1.f;
     prm.rcp = 1.f;
     prm.amax_bits = nullptr;
-    prm.flt_max = flt_max;
+    prm.rest.flt_max = flt_max;
     prm.clamp = clamp;
-    prm.seed = seed;
-    prm.offset = offset;
-    prm.elem_base = 0;
-    prm.partials = ws + 1;
+    prm.rest.seed = seed;
+    prm.rest.offset = offset;
+    prm.rest.elem_base = 0;
+    prm.rest.partials = ws + 1;
     prm.npart = (uint32_t)nb;
-    prm.amax_pub = ws;
+    prm.rest.amax_pub = ws;
     return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
   }
   return fpemu_quantize_per_tensor(in, out, n, dtype, fmt, rmode, flt_max, clamp, ws, seed, offset, stream);

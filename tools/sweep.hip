@@ -3,7 +3,8 @@
 // fpemu_device.hpp; variants differ only in how bytes move.  Interleaved rounds in ONE process
 // (cdna_hip_programming.md rule 24); prints median and min GB/s per variant.
 //
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o tools/sweep tools/sweep.hip
+//   make -C fp8-emulation-toolkit_amd/csrc && tools/build_sweep.sh   (links libfpemu_hip.so; also builds
+//   tools/sweep_pl with gfx950 kernarg preload on the sweep's own kernels)
 //   ./tools/sweep [elements=268435456] [rounds=15]
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -114,9 +115,9 @@ __global__ __launch_bounds__(BLOCK) void k_perm(const u32x4 *in, u32x4 *out, uin
 // LP / SP index into the modifier tables below.
 #define LD_ASM(mods) asm volatile("global_load_dwordx4 %0, %1, off " mods "\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory")
 #define ST_ASM(mods) asm volatile("global_store_dwordx4 %0, %1, off " mods : : "v"(dst), "v"(o) : "memory")
-template <int LP, int SP, bool COMPUTE>
-__global__ __launch_bounds__(256) void k_pol(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+template <int LP, int SP, bool COMPUTE, int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK) void k_pol(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
+  const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= nvec) return;
   const u32x4 *src = in + i;
   u32x4 *dst = out + i;
@@ -244,23 +245,37 @@ int main(int argc, char **argv) {
   // grid = 0 means "one iteration per wave": grid = nvec / (64*U*waves_per_block)
   auto noloop = [&](int block, int U) { return (int)(nvec / (64ull * U * (block / 64))); };
   const int g1 = noloop(256, 1);
+  add("pol ld nt / st sc1nt B256 (x1)", k_pol<1, 4, true>, 256, g1, 0);
+  add("pol ld nt / st sc1nt B128", k_pol<1, 4, true, 128>, 128, noloop(128, 1), 0);
+  add("pol ld nt / st sc1nt B64", k_pol<1, 4, true, 64>, 64, noloop(64, 1), 0);
+  add("pol ld nt / st sc1nt B512", k_pol<1, 4, true, 512>, 512, noloop(512, 1), 0);
+  add("cast noloop U1 B256 builtin nt/nt", k_wave<256, 1, true, true, true>, 256, g1, 0);
+  add("cast noloop U1 B128 builtin nt/nt", k_wave<128, 1, true, true, true>, 128, noloop(128, 1), 0);
+  add("cast noloop U1 B64 builtin nt/nt", k_wave<64, 1, true, true, true>, 64, noloop(64, 1), 0);
+  add("copy pol ld nt / st sc1nt", k_pol<1, 4, false>, 256, g1, 0);
   add("READ-only nt U1 (x2 scale)", k_read<true>, 256, g1, 0);
-  add("amax B256 VPT1 cond", k_amax<256, 1, true>, 256, noloop(256, 1), 0);
-  add("amax B256 VPT2 cond", k_amax<256, 2, true>, 256, noloop(256, 2), 0);
-  add("amax B256 VPT4 cond", k_amax<256, 4, true>, 256, noloop(256, 4), 0);
-  add("amax B256 VPT8 cond", k_amax<256, 8, true>, 256, noloop(256, 8), 0);
-  add("amax B256 VPT16 cond", k_amax<256, 16, true>, 256, noloop(256, 16), 0);
-  add("amax B512 VPT4 cond", k_amax<512, 4, true>, 512, noloop(512, 4), 0);
-  add("amax B1024 VPT2 cond", k_amax<1024, 2, true>, 1024, noloop(1024, 2), 0);
-  add("amax B1024 VPT4 cond", k_amax<1024, 4, true>, 1024, noloop(1024, 4), 0);
-  add("amax B64 VPT4 cond", k_amax<64, 4, true>, 64, noloop(64, 4), 0);
-  add("amax B256 VPT4 always-atomic", k_amax<256, 4, false>, 256, noloop(256, 4), 0);
-  add("amax B256 VPT8 always-atomic", k_amax<256, 8, false>, 256, noloop(256, 8), 0);
-
+  add("amax B256 VPT8 cond (x2 scale)", k_amax<256, 8, true>, 256, noloop(256, 8), 0);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  std::vector<float> memcpy_ms, lib_ms, lib_inplace_ms, lib_sr_ms;
+  std::vector<float> memcpy_ms, lib_ms, lib_inplace_ms, lib_sr_ms, lib_scaled_ms, lib_ws_ms;
+  uint32_t *ws;
+  CK(hipMalloc(&ws, 4096));
+  auto time_scaled = [&](std::vector<float> &acc, int r, bool two_launch) {
+    auto once = [&]() {
+      int rc = two_launch ? fpemu_quantize_per_tensor_ws(in, out, n, FPEMU_F32, FPEMU_FMT_E4M3, FPEMU_RNE, 448.f, 1, ws, 1024, 1, 0, nullptr)
+                          : fpemu_quantize_per_tensor(in, out, n, FPEMU_F32, FPEMU_FMT_E4M3, FPEMU_RNE, 448.f, 1, ws, 1, 0, nullptr);
+      if (rc != 0) { printf("scaled rc=%d %s\n", rc, fpemu_last_error()); exit(1); }
+    };
+    once();
+    CK(hipEventRecord(e0, 0));
+    for (int k = 0; k < REPS; k++) once();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 2) acc.push_back(ms / REPS);
+  };
   auto time_lib = [&](std::vector<float> &acc, int r, void *o, int rmode) {
     int rc = fpemu_cast(in, o, n, FPEMU_F32, FPEMU_FMT_E4M3, rmode, 1.0f, 1, 0, 0, nullptr);
     if (rc != 0) { printf("fpemu_cast rc=%d %s\n", rc, fpemu_last_error()); exit(1); }
@@ -290,6 +305,9 @@ int main(int argc, char **argv) {
     }
     time_lib(lib_ms, r, out, FPEMU_RNE);
     time_lib(lib_sr_ms, r, out, FPEMU_STOCHASTIC);
+    time_lib(lib_inplace_ms, r, in, FPEMU_RNE);  // E4M3_RNE is idempotent: in-place keeps the data valid
+    time_scaled(lib_scaled_ms, r, false);
+    time_scaled(lib_ws_ms, r, true);
     CK(hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, 0));
     CK(hipEventRecord(e0, 0));
     for (int k = 0; k < REPS; k++) CK(hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, 0));
@@ -310,6 +328,9 @@ int main(int argc, char **argv) {
   for (auto &v : vs) report(v.name, v.ms);
   report("LIB fpemu_cast E4M3_RNE out-of-place", lib_ms);
   report("LIB fpemu_cast E4M3_STOCHASTIC", lib_sr_ms);
+  report("LIB fpemu_cast E4M3_RNE in-place", lib_inplace_ms);
+  report("LIB per-tensor zero+amax+cast (8B scale; x1.5 = 12B)", lib_scaled_ms);
+  report("LIB per-tensor_ws partials+cast (8B scale; x1.5)", lib_ws_ms);
   report("hipMemcpyAsync D2D", memcpy_ms);
   return 0;
 }
