@@ -38,6 +38,7 @@ constexpr int kAmaxMaxBlocks = 256 * 16;       // amax: looped, one atomic per b
 constexpr uint64_t kSmallVectors = 2048;       // <= this many 16-byte vectors: fused one-workgroup path (the
                                                // workgroup holds them in registers: fpemu_rows.hip, rows_reg_kernel)
 constexpr uint64_t kKeepBytes = 160ull << 20;  // fused amax -> cast: tensors up to this size keep cache residency
+constexpr uint64_t kPartialsBytes = 768ull << 20;  // above: zero + atomic amax + cast is as fast or faster (1 GiB: 0.489 vs 0.503 ms)
 constexpr uint64_t kMaxPartials = 256;  // one per CU; measured best of 128 / 256 / 512 / 1024 / 2048
 constexpr int kNoRowsKernel = -100;            // fpemu_rows_launch_: no kernel for this fmt/rmode/dtype
 
@@ -68,6 +69,23 @@ struct CastParams {
   } rest;
 };
 
+// Workgroup size of the flat cast kernels (the amax and rows kernels keep kBlock).  Measured on MI355X at
+// 1 GiB (tools/sweep.hip against libraries built with each size): the one-vector-per-lane deterministic cast
+// runs 6.74 / 6.84 / 6.79 TB/s with 256 / 128 / 64 threads -- smaller workgroups retire and are replaced at a
+// finer grain, which keeps more requests in flight; the stochastic cast (four vectors per lane) prefers 256.
+#ifndef FPEMU_CAST_BLOCK_DET
+#define FPEMU_CAST_BLOCK_DET 128
+#endif
+#ifndef FPEMU_CAST_BLOCK_SR
+#define FPEMU_CAST_BLOCK_SR 256
+#endif
+#ifndef FPEMU_CAST_BLOCK_16
+#define FPEMU_CAST_BLOCK_16 256
+#endif
+constexpr int cast_block(int rm, int dt) {
+  return rm == STOCHASTIC ? FPEMU_CAST_BLOCK_SR : (dt == FPEMU_F32 ? FPEMU_CAST_BLOCK_DET : FPEMU_CAST_BLOCK_16);
+}
+
 // Random bits for element e (0..V-1) of slot s from the lane's Philox results of this superblock.
 template <int FMT, unsigned V, int NCALLS>
 __device__ __forceinline__ uint32_t lane_noise(const Philox4 (&p)[NCALLS], unsigned slot, unsigned e) {
@@ -90,7 +108,9 @@ struct GivenScale {
   __device__ __forceinline__ void resolve(float &s, float &r) const { s = scale; r = rcp; }
 };
 
+template <int kCastBlock>
 struct DeviceScale {  // cast_kernel: scale given, or derived from a device word / per-block maxima
+  static constexpr int kCastWaves = kCastBlock / 64;
   float scale, rcp;
   const uint32_t *amax_bits;
   uint32_t npart;
@@ -100,18 +120,21 @@ struct DeviceScale {  // cast_kernel: scale given, or derived from a device word
     s = scale;
     r = rcp;
     if (npart != 0u) {  // uniform over the launch
-      __shared__ uint32_t pmax[kWavesPerBlock];
+      __shared__ uint32_t pmax[kCastWaves];
       uint32_t m = 0u;
-      for (uint32_t i = threadIdx.x; i < npart; i += kBlock) {
+      for (uint32_t i = threadIdx.x; i < npart; i += kCastBlock) {
         const uint32_t v = rest->partials[i];
         m = m > v ? m : v;
       }
       m = wave_max_u32(m);
-      if ((threadIdx.x & 63u) == 0u) pmax[threadIdx.x >> 6] = m;
-      __syncthreads();
-      uint32_t mx = pmax[0];
+      uint32_t mx = m;
+      if constexpr (kCastWaves > 1) {
+        if ((threadIdx.x & 63u) == 0u) pmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        mx = pmax[0];
 #pragma unroll
-      for (int w = 1; w < kWavesPerBlock; w++) mx = mx > pmax[w] ? mx : pmax[w];
+        for (int w = 1; w < kCastWaves; w++) mx = mx > pmax[w] ? mx : pmax[w];
+      }
       if (blockIdx.x == 0 && threadIdx.x == 0) *rest->amax_pub = mx;
       s = scale_from_amax(mx, rest->flt_max, clamp != 0);
       r = scale_reciprocal(s);
@@ -124,7 +147,7 @@ struct DeviceScale {  // cast_kernel: scale given, or derived from a device word
 
 // The streaming body: workgroup `blk` of `nblk` that share one buffer (cast_kernel: the whole grid;
 // cast_multi_kernel: the tensor's share of the grid).
-template <int FMT, int RM, int DT, class ScaleSrc>
+template <int FMT, int RM, int DT, int kCastBlock, class ScaleSrc>
 __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_t nsb, uint64_t n,
                                             const ScaleSrc &src, uint64_t seed, uint64_t offset, uint64_t elem_base,
                                             unsigned blk, unsigned nblk) {
@@ -133,13 +156,14 @@ __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_
   constexpr uint64_t SB_ELEMS = (uint64_t)V * 64u * U;
   constexpr bool SR = (RM == STOCHASTIC);
   constexpr int NCALLS = SR ? (int)(4u * V * noise_bytes<FMT>() / 16u) : 1;
+  constexpr int kCastWaves = kCastBlock / 64;
 
   const unsigned lane = threadIdx.x & 63u;
   const u32x4 *in = reinterpret_cast<const u32x4 *>(in_);
   u32x4 *out = reinterpret_cast<u32x4 *>(out_);
 
   // first (normally the only) superblock of this wave: issue its loads before anything else
-  uint64_t sb = (uint64_t)blk * kWavesPerBlock + (threadIdx.x >> 6);
+  uint64_t sb = (uint64_t)blk * kCastWaves + (threadIdx.x >> 6);
   bool have = sb < nsb;
   u32x4 v[U];
   if (have) {
@@ -151,7 +175,7 @@ __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_
   float scale, rcp;
   src.resolve(scale, rcp);
 
-  const uint64_t nwaves = (uint64_t)nblk * kWavesPerBlock;
+  const uint64_t nwaves = (uint64_t)nblk * kCastWaves;
   const uint64_t sb_base = elem_base / SB_ELEMS;
   while (have) {
     const uint64_t v0 = sb * (64u * U) + lane;
@@ -196,8 +220,8 @@ __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_
   using elem_t = typename Storage<DT>::elem;
   const elem_t *ein = reinterpret_cast<const elem_t *>(in_);
   elem_t *eout = reinterpret_cast<elem_t *>(out_);
-  const uint64_t tstride = (uint64_t)nblk * kBlock;
-  for (uint64_t i = nsb * SB_ELEMS + (uint64_t)blk * kBlock + threadIdx.x; i < n; i += tstride) {
+  const uint64_t tstride = (uint64_t)nblk * kCastBlock;
+  for (uint64_t i = nsb * SB_ELEMS + (uint64_t)blk * kCastBlock + threadIdx.x; i < n; i += tstride) {
     uint32_t rnd = 0u;
     if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, offset, elem_base + i);
     if constexpr (DT == FPEMU_F32) {
@@ -209,12 +233,12 @@ __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_
 }
 
 // The first ten arguments are 14 dwords: the part of the kernarg segment gfx950 preloads into SGPRs.
-template <int FMT, int RM, int DT>
-__global__ __launch_bounds__(kBlock) void cast_kernel(const void *in_, void *out_, uint64_t nsb, uint64_t n,
+template <int FMT, int RM, int DT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void cast_kernel(const void *in_, void *out_, uint64_t nsb, uint64_t n,
                                                       float scale, float rcp, const uint32_t *amax_bits,
                                                       uint32_t npart, int clamp, CastParams::Rest rest) {
-  const DeviceScale src{scale, rcp, amax_bits, npart, clamp, &rest};
-  cast_blocks<FMT, RM, DT>(in_, out_, nsb, n, src, rest.seed, rest.offset, rest.elem_base, blockIdx.x,
+  const DeviceScale<BLOCK> src{scale, rcp, amax_bits, npart, clamp, &rest};
+  cast_blocks<FMT, RM, DT, BLOCK>(in_, out_, nsb, n, src, rest.seed, rest.offset, rest.elem_base, blockIdx.x,
                            gridDim.x);
 }
 
@@ -235,12 +259,12 @@ struct MultiTable {
 };
 
 template <int FMT, int RM, int DT>
-__global__ __launch_bounds__(kBlock) void cast_multi_kernel(MultiTable tab, float scale, float rcp, uint64_t seed,
+__global__ __launch_bounds__(cast_block(RM, DT)) void cast_multi_kernel(MultiTable tab, float scale, float rcp, uint64_t seed,
                                                             uint64_t offset) {
   unsigned t = 0;
   while (t + 1u < tab.count && blockIdx.x >= tab.blk_end[t]) t++;  // uniform: scalar loads and compares
   const unsigned first = t == 0u ? 0u : tab.blk_end[t - 1u];
-  cast_blocks<FMT, RM, DT>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], GivenScale{scale, rcp}, seed, offset + t, 0,
+  cast_blocks<FMT, RM, DT, cast_block(RM, DT)>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], GivenScale{scale, rcp}, seed, offset + t, 0,
                            blockIdx.x - first, tab.blk_end[t] - first);
 }
 
@@ -330,9 +354,11 @@ __global__ void zero_word_kernel(uint32_t *w) { *w = 0u; }
 typedef void (*cast_fn)(const void *, void *, uint64_t, uint64_t, float, float, const uint32_t *, uint32_t, int,
                         CastParams::Rest);
 
-template <int DT> cast_fn pick_cast(int fmt, int rm) {
+// wide = true: the 256-thread build of a kernel whose default workgroup is smaller (the per-block-maxima
+// path: every workgroup reduces the maxima first, which smaller workgroups repeat more often per byte)
+template <int DT> cast_fn pick_cast(int fmt, int rm, bool wide) {
 #define FPEMU_CASE(F, R) \
-  if (fmt == F && rm == R) return cast_kernel<F, R, DT>;
+  if (fmt == F && rm == R) return wide ? cast_kernel<F, R, DT, kBlock> : cast_kernel<F, R, DT, cast_block(R, DT)>;
   FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
   FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
   FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
@@ -368,11 +394,11 @@ template <int DT> cast_multi_fn pick_cast_multi(int fmt, int rm) {
   return nullptr;
 }
 
-cast_fn pick_cast_dt(int dtype, int fmt, int rm) {
+cast_fn pick_cast_dt(int dtype, int fmt, int rm, bool wide = false) {
   switch (dtype) {
-    case FPEMU_F32: return pick_cast<FPEMU_F32>(fmt, rm);
-    case FPEMU_F16: return pick_cast<FPEMU_F16>(fmt, rm);
-    case FPEMU_BF16: return pick_cast<FPEMU_BF16>(fmt, rm);
+    case FPEMU_F32: return pick_cast<FPEMU_F32>(fmt, rm, wide);
+    case FPEMU_F16: return pick_cast<FPEMU_F16>(fmt, rm, wide);
+    case FPEMU_BF16: return pick_cast<FPEMU_BF16>(fmt, rm, wide);
     default: return nullptr;
   }
 }
@@ -385,7 +411,8 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
   if (n == 0) return FPEMU_OK;
   if (in == nullptr || out == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast: null buffer");
   if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_cast: bad dtype id");
-  cast_fn fn = pick_cast_dt(dtype, fmt, rmode);
+  const bool wide = prm.npart != 0u;
+  cast_fn fn = pick_cast_dt(dtype, fmt, rmode, wide);
   if (fn == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast: format / rounding-mode pair not defined");
   const unsigned es = elem_size(dtype);
   if (((uintptr_t)in % es) || ((uintptr_t)out % es))
@@ -396,13 +423,15 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
                       (rmode != STOCHASTIC || (prm.rest.elem_base % sb_elems) == 0);
   const uint64_t nsb = vec_ok ? n / sb_elems : 0;
   const uint64_t tail = n - nsb * sb_elems;
-  uint64_t blocks = (nsb + kWavesPerBlock - 1) / kWavesPerBlock;
-  const uint64_t tail_blocks = (tail + kBlock - 1) / kBlock;
+  const unsigned kCastBlock = wide ? (unsigned)kBlock : (unsigned)cast_block(rmode, dtype);
+  const unsigned kCastWaves = kCastBlock / 64u;
+  uint64_t blocks = (nsb + kCastWaves - 1) / kCastWaves;
+  const uint64_t tail_blocks = (tail + kCastBlock - 1) / kCastBlock;
   if (blocks < tail_blocks) blocks = tail_blocks;
   if (blocks > (uint64_t)max_blocks()) blocks = (uint64_t)max_blocks();
   if (blocks == 0) blocks = 1;
 
-  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, in, out, nsb,
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kCastBlock), 0, (hipStream_t)stream, in, out, nsb,
                      n, prm.scale, prm.rcp, prm.amax_bits, prm.npart, prm.clamp, prm.rest);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
@@ -502,6 +531,7 @@ int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, i
   }
   const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 64u * (unsigned)slots_per_wave(rmode, dtype);
   const float rcp = (float)(1.0 / (double)scale);  // cpp:714
+  const unsigned kCastBlock = (unsigned)cast_block(rmode, dtype), kCastWaves = kCastBlock / 64u;
   uint64_t i = 0;
   while (i < count) {
     MultiTable tab;
@@ -514,8 +544,8 @@ int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, i
       const bool vec_ok = (((uintptr_t)t.in | (uintptr_t)t.out) % 16u) == 0;
       const uint64_t nsb = vec_ok ? t.n / sb_elems : 0;
       const uint64_t tail = t.n - nsb * sb_elems;
-      uint64_t b = (nsb + kWavesPerBlock - 1) / kWavesPerBlock;
-      const uint64_t tb = (tail + kBlock - 1) / kBlock;
+      uint64_t b = (nsb + kCastWaves - 1) / kCastWaves;
+      const uint64_t tb = (tail + kCastBlock - 1) / kCastBlock;
       if (b < tb) b = tb;
       if (b > (uint64_t)max_blocks()) b = (uint64_t)max_blocks();
       if (blocks + b > 0x7FFFFFFFull) {
@@ -531,7 +561,7 @@ int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, i
     }
     tab.count = k;
     if (blocks != 0) {
-      hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, tab, scale, rcp, seed,
+      hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kCastBlock), 0, (hipStream_t)stream, tab, scale, rcp, seed,
                          offset + first);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
@@ -642,7 +672,7 @@ int fpemu_quantize_per_tensor_ws(const void *in, void *out, uint64_t n, int dtyp
                        ((uintptr_t)in % elem_size(dtype)) == 0 && ((uintptr_t)out % elem_size(dtype)) == 0;
   // above the one-workgroup size: two launches -- per-block maxima into ws[1..], then the cast, whose
   // blocks each reduce those maxima (L2 hits) -- instead of zero + atomic amax + cast
-  if (args_ok && n > kSmallVectors * vec_elems(dtype) && ws_words >= 2 &&
+  if (args_ok && n > kSmallVectors * vec_elems(dtype) && n * elem_size(dtype) <= kPartialsBytes && ws_words >= 2 &&
       pick_cast_dt(dtype, fmt, rmode) != nullptr && fmt != BF16 && fmt != FP16 && fmt != FP16_DAZ) {
     const bool vec_ok = ((uintptr_t)in % 16u) == 0;
     const uint64_t nvec = vec_ok ? n / vec_elems(dtype) : 0;

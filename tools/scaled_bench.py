@@ -9,6 +9,8 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fp8-emulation-toolkit_amd"))
 from mpemu.pytquant.hip import _binding as hip  # noqa: E402
 
+hip._SO = os.environ.get("FPEMU_LIB", hip._SO)  # tuning aid: a library built with other geometry constants
+
 f, r = hip.parse_mode("E4M3_RNE")
 for mib in (0.25, 3, 16, 32, 64, 128, 256, 512, 1024):
     n = int(mib * (1 << 20)) // 4

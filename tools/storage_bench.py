@@ -7,6 +7,8 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fp8-emulation-toolkit_amd"))
 from mpemu.pytquant.hip import _binding as hip  # noqa: E402
 
+hip._SO = os.environ.get("FPEMU_LIB", hip._SO)  # tuning aid: a library built with other geometry constants
+
 n = 1 << 27
 for dt, bpe in ((torch.float32, 8), (torch.float16, 4), (torch.bfloat16, 4)):
     x = (torch.randn(n, device="cuda") * 3).to(dt)
