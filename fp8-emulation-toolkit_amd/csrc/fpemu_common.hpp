@@ -61,6 +61,59 @@ template <int DT> __device__ __forceinline__ uint32_t pack_pair16(float y0, floa
 }
 
 
+// One 16-byte vector of storage DT through the cast.  `noise` supplies the random bits of the vector's elements
+// (used by stochastic modes only): one(e) for element e, pair(e) for elements e and e + 1 (e even), one per
+// 16-bit half.  Formats with a packed quantiser (fpemu_device.hpp, has_packed_quant) go two elements at a time.
+struct NoNoise {
+  __device__ __forceinline__ uint32_t one(unsigned) const { return 0u; }
+  __device__ __forceinline__ uint32_t pair(unsigned) const { return 0u; }
+};
+
+template <int FMT, int RM, int DT, class Noise>
+__device__ __forceinline__ u32x4 cast_vector(const u32x4 v, float scale, float rcp, const Noise &noise) {
+  constexpr bool SR = (RM == STOCHASTIC);
+  u32x4 o;
+  if constexpr (has_packed_quant<FMT, RM>() && DT == FPEMU_F32) {
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      const uint32_t rnd2 = SR ? noise.pair(j) : 0u;
+      float y0, y1;
+      cast_pair<FMT, RM>(u2f(v[j]), u2f(v[j + 1]), scale, rcp, rnd2, y0, y1);
+      o[j] = f2u(y0);
+      o[j + 1] = f2u(y1);
+    }
+  } else if constexpr (has_packed_quant<FMT, RM>()) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {  // 16-bit storage: each dword is a pair already
+      const uint32_t rnd2 = SR ? noise.pair(2 * j) : 0u;
+      float y0, y1;
+      cast_pair<FMT, RM>(load_elem16<DT>(v[j] & 0xFFFFu), load_elem16<DT>(v[j] >> 16), scale, rcp, rnd2, y0, y1);
+      o[j] = pack_pair16<DT>(y0, y1);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if constexpr (DT == FPEMU_F32) {
+        o[j] = f2u(cast_one<FMT, RM>(u2f(v[j]), scale, rcp, SR ? noise.one(j) : 0u));
+      } else {
+        const float y0 = cast_one<FMT, RM>(load_elem16<DT>(v[j] & 0xFFFFu), scale, rcp, SR ? noise.one(2 * j) : 0u);
+        const float y1 = cast_one<FMT, RM>(load_elem16<DT>(v[j] >> 16), scale, rcp, SR ? noise.one(2 * j + 1) : 0u);
+        o[j] = pack_pair16<DT>(y0, y1);
+      }
+    }
+  }
+  return o;
+}
+
+// Noise of a vector whose first element has index `base` in the (seed, call) stream: the general form
+// (rows / blocks, where a vector's position in its row decides the counter).
+template <int FMT, unsigned V>
+struct ElemNoise {
+  uint64_t seed, call, base;
+  __device__ __forceinline__ uint32_t one(unsigned e) const { return rand_bits_elem<FMT, V>(seed, call, base + e); }
+  __device__ __forceinline__ uint32_t pair(unsigned e) const { return one(e) | (one(e + 1u) << 16); }
+};
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t m) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {

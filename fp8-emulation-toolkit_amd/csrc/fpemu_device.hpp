@@ -200,6 +200,114 @@ __device__ __forceinline__ float cast_one(float x, float scale, float rcp, uint3
 }
 
 // ---------------------------------------------------------------------------------------------
+// Packed form: TWO fp16 patterns in one VGPR, quantised by gfx950's packed 16-bit VALU ops (v_pk_add_u16,
+// v_pk_lshlrev_b16, v_pk_min_u16, ...), so the integer part of the cast costs one instruction per PAIR of
+// elements.  There is no packed compare / select: the selects of the scalar form become 0/1 gates
+//     ge(a, c) = min(a -sat (c - 1), 1)        1 iff a >= c      (v_pk_sub_u16 clamp, v_pk_min_u16)
+// multiplied in (v_pk_mul_lo_u16), caps (v_pk_min_u16 against a saturating difference) or masks; the
+// saturation is an unsigned min (rounding is monotone and the largest value is representable, so
+// round(a) >= SAT exactly when a >= SAT).  Same results as quant_h for
+// every pattern (tests: all 65 536 fp16 patterns per mode through both forms).  Defined for the three FP8
+// formats under RTZ / RNE / STOCHASTIC -- the modes of BASELINE config 2; everything else runs quant_h per half.
+// ---------------------------------------------------------------------------------------------
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+
+template <int FMT, int RM>
+__host__ __device__ constexpr bool has_packed_quant() {
+  return (FMT == E5M2 || FMT == E4M3 || FMT == E3M4) && (RM == RTZ || RM == RNE || RM == STOCHASTIC);
+}
+
+__device__ __forceinline__ u16x2 splat16(uint32_t c) { return u16x2{(uint16_t)c, (uint16_t)c}; }
+// 1 iff a >= c (c >= 1), per half.  The min is an asm statement so that the gate stays a value of its own: left
+// visible, LLVM rewrites min(x, 1) * y into per-half compares and selects (v_cmp_u16 + v_cndmask + v_perm: five or
+// six instructions where the packed min and multiply are two).
+__device__ __forceinline__ u16x2 ge_gate(u16x2 a, uint32_t c) {
+  const uint32_t t = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(a, splat16(c - 1u)));
+  uint32_t g;
+  asm volatile("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(g) : "v"(t));
+  return __builtin_bit_cast(u16x2, g);
+}
+
+// rnd: per half, >= 8 random bits in the low byte (ignored unless STOCHASTIC)
+template <int RM>
+__device__ __forceinline__ u16x2 quant2_e5m2(u16x2 h, u16x2 rnd) {
+  if constexpr (RM == RTZ) {
+    return h & splat16(0xFF00u);  // Inf / NaN: h & 0xFF00 as well
+  } else {
+    const u16x2 a = h & splat16(0x7FFFu);
+    const u16x2 rne = ((h >> splat16(8u)) & splat16(1u)) + splat16(0x7Fu);  // + 0x7F + kept LSB, then truncate
+    u16x2 inc = rne;
+    if constexpr (RM == STOCHASTIC) {
+      const u16x2 nrm = ge_gate(a, 0x0400u);  // fp16 normals take the noise, fp16 denormals RNE (cpp:739-742)
+      inc = rne + nrm * ((rnd & splat16(0xFFu)) - rne);
+    }
+    // Inf / NaN take no increment, finite values the whole of it: inc is capped at 0x7C00 - a (saturating, so 0
+    // from Inf up).  A cap that bites means a + inc would pass 0x7C00 by less than 0x100: the truncated result
+    // is 0x7C00 either way.
+    inc = __builtin_elementwise_min(inc, __builtin_elementwise_sub_sat(splat16(0x7C00u), a));
+    return (h + inc) & splat16(0xFF00u);
+  }
+}
+
+template <int RM, int K, uint32_t SAT, uint32_t FLUSH, int ENORM>
+__device__ __forceinline__ u16x2 quant2_e4m3_e3m4(u16x2 h, u16x2 rnd) {
+  constexpr uint32_t LOWM = (1u << K) - 1u;
+  constexpr int DMAX = ENORM - (int)(FLUSH >> 10);  // largest pseudo-subnormal shift (3 / 4)
+  static_assert((FLUSH & 0x3FFu) == 0u, "the flush bound is a power of two");
+  const u16x2 a = h & splat16(0x7FFFu);
+  // pseudo-subnormals: clear the d = ENORM - expfield low mantissa bits; below the flush bound (d > DMAX)
+  // clear everything -- and a cleared magnitude rounds to 0 in every mode.  mask = -((1 << d) & (2^(DMAX+1) - 1)):
+  // 0xFFFF << d for d <= DMAX, 0 above.
+  const i16x2 e = __builtin_bit_cast(i16x2, a >> splat16(10u));
+  const i16x2 d = __builtin_elementwise_max(i16x2{(int16_t)ENORM, (int16_t)ENORM} - e, i16x2{0, 0});
+  const u16x2 bit = (splat16(1u) << __builtin_bit_cast(u16x2, d)) & splat16((2u << DMAX) - 1u);
+  const u16x2 m = a & (splat16(0u) - bit);
+  u16x2 r = m;
+  if constexpr (RM == RNE) r = m + ((m >> splat16((uint32_t)K)) & splat16(1u)) + splat16((1u << (K - 1)) - 1u);
+  else if constexpr (RM == STOCHASTIC) r = m + (rnd & splat16(LOWM));
+  r &= splat16(~LOWM);
+  r = __builtin_elementwise_min(r, splat16(SAT));           // >= max, Inf and NaN saturate
+  return r | (h & splat16(0x8000u));
+}
+
+template <int FMT, int RM>
+__device__ __forceinline__ u16x2 quant_h2(u16x2 h, u16x2 rnd) {
+  if constexpr (FMT == E5M2) return quant2_e5m2<RM>(h, rnd);
+  else if constexpr (FMT == E4M3) return quant2_e4m3_e3m4<RM, 7, 0x5F00u, 0x1800u, 9>(h, rnd);
+  else return quant2_e4m3_e3m4<RM, 6, 0x4F80u, 0x2400u, 13>(h, rnd);
+}
+
+// f32( f16 half of q ) * rcp as ONE instruction: v_fma_mix_f32 reads the half straight out of the packed
+// register (op_sel) and rounds the product once to fp32 -- the same value as v_cvt_f32_f16 (exact) followed by
+// v_mul_f32.  The addend is -0.0 (held in an SGPR), which leaves the product's sign alone (x*y + -0 == x*y for
+// every x*y, including both zeros); a +0 addend would turn a -0 product into +0.
+template <int HI>
+__device__ __forceinline__ float mix_mul(uint32_t q, float rcp) {
+  float r;
+  const float nz = -0.0f;
+  if constexpr (HI) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(q), "v"(rcp), "s"(nz));
+  else asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(q), "v"(rcp), "s"(nz));
+  return r;
+}
+
+// Two elements, fp32 in -> fp32 out; rnd2: the two elements' noise, one per 16-bit half.
+// Only for has_packed_quant<FMT, RM>().
+template <int FMT, int RM>
+__device__ __forceinline__ void cast_pair(float x0, float x1, float scale, float rcp, uint32_t rnd2, float &y0,
+                                          float &y1) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+  float p0 = x0 * scale, p1 = x1 * scale;
+  asm volatile("" : "+v"(p0), "+v"(p1));  // the fp32 products are values of their own (see cast_one)
+  const h16x2 hh = __builtin_convertvector(f32x2{p0, p1}, h16x2);  // v_cvt_pk_f16_f32: RNE, denormals kept
+  const u16x2 q = quant_h2<FMT, RM>(__builtin_bit_cast(u16x2, hh), __builtin_bit_cast(u16x2, rnd2));
+  const uint32_t qq = __builtin_bit_cast(uint32_t, q);
+  y0 = mix_mul<0>(qq, rcp);
+  y1 = mix_mul<1>(qq, rcp);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Philox4x32-10, counter-based: replaces the shared mutable xoshiro state of the reference
 // (cpp:41-88, hip/fpemu_kernels.hip:47-102), which races.  key = seed, counter = (ctr, offset).
 // ---------------------------------------------------------------------------------------------

@@ -95,6 +95,27 @@ __device__ __forceinline__ uint32_t lane_noise(const Philox4 (&p)[NCALLS], unsig
   return w;  // consumers mask the bits they use
 }
 
+// The noise bytes of elements e and e + 1 (e even) of slot s, one per 16-bit half: the packed quantisers'
+// operand.  Both bytes lie in one Philox word; v_perm_b32 spreads them (selector 0x0C = constant zero byte).
+template <int FMT, unsigned V, int NCALLS>
+__device__ __forceinline__ uint32_t lane_noise_pair(const Philox4 (&p)[NCALLS], unsigned slot, unsigned e) {
+  static_assert(noise_bytes<FMT>() == 1, "packed noise is one byte per element");
+  const unsigned pos = slot * V + e;          // compile-time after unrolling; even
+  const uint32_t w = philox_word(p[pos / 16u], (pos % 16u) / 4u);
+  return __builtin_amdgcn_perm(0u, w, (pos % 4u) == 0u ? 0x0C010C00u : 0x0C030C02u);
+}
+
+template <int FMT, unsigned V, int NCALLS>
+struct LaneNoise {  // cast_vector's noise source in the flat cast: slot `slot` of the lane's Philox results
+  const Philox4 (&p)[NCALLS];
+  unsigned slot;
+  __device__ __forceinline__ uint32_t one(unsigned e) const { return lane_noise<FMT, V, NCALLS>(p, slot, e); }
+  __device__ __forceinline__ uint32_t pair(unsigned e) const {
+    if constexpr (noise_bytes<FMT>() == 1) return lane_noise_pair<FMT, V, NCALLS>(p, slot, e);
+    else return 0u;  // two-byte noise: formats without a packed quantiser never ask
+  }
+};
+
 // 16-byte vectors per lane: 4 for stochastic modes (the noise layout's superblock); deterministic fp32
 // storage 1 (pure stream, measured fastest); deterministic 16-bit storage 2 (twice the ALU work per byte:
 // a second independent vector per lane hides it)
@@ -188,21 +209,7 @@ __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_
 
 #pragma unroll
     for (int s = 0; s < U; s++) {
-      u32x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if constexpr (DT == FPEMU_F32) {
-          const uint32_t rnd = SR ? lane_noise<FMT, V, NCALLS>(p, s, j) : 0u;
-          o[j] = f2u(cast_one<FMT, RM>(u2f(v[s][j]), scale, rcp, rnd));
-        } else {
-          const uint32_t w = v[s][j];
-          const uint32_t r0 = SR ? lane_noise<FMT, V, NCALLS>(p, s, 2 * j) : 0u;
-          const uint32_t r1 = SR ? lane_noise<FMT, V, NCALLS>(p, s, 2 * j + 1) : 0u;
-          const float y0 = cast_one<FMT, RM>(load_elem16<DT>(w & 0xFFFFu), scale, rcp, r0);
-          const float y1 = cast_one<FMT, RM>(load_elem16<DT>(w >> 16), scale, rcp, r1);
-          o[j] = pack_pair16<DT>(y0, y1);
-        }
-      }
+      const u32x4 o = cast_vector<FMT, RM, DT>(v[s], scale, rcp, LaneNoise<FMT, V, NCALLS>{p, (unsigned)s});
       store_stream(&out[v0 + (uint64_t)s * 64u], o);
     }
 

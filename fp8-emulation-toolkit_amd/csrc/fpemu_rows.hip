@@ -99,25 +99,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out
   const uint64_t roff = offset + row;
 
   for (uint64_t i = t; i < nvec; i += TS) {
-    const u32x4 v = vin[i];
-    u32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if constexpr (DT == FPEMU_F32) {
-        uint32_t rnd = 0u;
-        if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, i * V + j);
-        o[j] = f2u(cast_one<FMT, RM>(u2f(v[j]), scale, rcp, rnd));
-      } else {
-        uint32_t r0 = 0u, r1 = 0u;
-        if constexpr (SR) {
-          r0 = rand_bits_elem<FMT, V>(seed, roff, i * V + 2 * j);
-          r1 = rand_bits_elem<FMT, V>(seed, roff, i * V + 2 * j + 1);
-        }
-        const float y0 = cast_one<FMT, RM>(load_elem16<DT>(v[j] & 0xFFFFu), scale, rcp, r0);
-        const float y1 = cast_one<FMT, RM>(load_elem16<DT>(v[j] >> 16), scale, rcp, r1);
-        o[j] = pack_pair16<DT>(y0, y1);
-      }
-    }
+    const u32x4 o = cast_vector<FMT, RM, DT>(vin[i], scale, rcp, ElemNoise<FMT, V>{seed, roff, i * V});
     vout[i] = o;
   }
 #pragma clang loop vectorize(disable) interleave(disable)
@@ -140,7 +122,6 @@ __global__ __launch_bounds__(kBlock) void rows_reg_kernel(const void *in_, void 
                                                           uint32_t nv, uint32_t lg, float flt_max, int policy,
                                                           uint64_t seed, uint64_t offset, uint32_t *amax_out) {
   constexpr unsigned V = Storage<DT>::V;
-  constexpr bool SR = (RM == STOCHASTIC);
   const unsigned G = 1u << lg;
   const unsigned t = threadIdx.x & (G - 1u);
   const uint64_t row = (((uint64_t)blockIdx.x * kBlock) >> lg) + (threadIdx.x >> lg);
@@ -192,24 +173,7 @@ __global__ __launch_bounds__(kBlock) void rows_reg_kernel(const void *in_, void 
 #pragma unroll
   for (int k = 0; k < NV; k++) {
     const uint32_t i = (uint32_t)k * G + t;
-    u32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if constexpr (DT == FPEMU_F32) {
-        uint32_t rnd = 0u;
-        if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, (uint64_t)i * V + j);
-        o[j] = f2u(cast_one<FMT, RM>(u2f(v[k][j]), scale, rcp, rnd));
-      } else {
-        uint32_t r0 = 0u, r1 = 0u;
-        if constexpr (SR) {
-          r0 = rand_bits_elem<FMT, V>(seed, roff, (uint64_t)i * V + 2 * j);
-          r1 = rand_bits_elem<FMT, V>(seed, roff, (uint64_t)i * V + 2 * j + 1);
-        }
-        const float y0 = cast_one<FMT, RM>(load_elem16<DT>(v[k][j] & 0xFFFFu), scale, rcp, r0);
-        const float y1 = cast_one<FMT, RM>(load_elem16<DT>(v[k][j] >> 16), scale, rcp, r1);
-        o[j] = pack_pair16<DT>(y0, y1);
-      }
-    }
+    const u32x4 o = cast_vector<FMT, RM, DT>(v[k], scale, rcp, ElemNoise<FMT, V>{seed, roff, (uint64_t)i * V});
     if (live && i < nv) store_stream(&vout[i], o);
   }
 }
