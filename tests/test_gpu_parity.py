@@ -40,6 +40,31 @@ def test_lut_all_fp16_patterns_vs_reference(hip, mode):
     assert_bits_equal(gpu_cast(hip, g["input_bits"].view(np.float32), mode), g[mode], mode)
 
 
+@pytest.mark.parametrize("mode", [m for m in DET_MODES + EXT_MODES + SR_MODES if m.split("_")[0] in ("E5M2", "E4M3", "E3M4")
+                                  and "DAZ" not in m and "IEEE" not in m])
+def test_packed_and_scalar_quantisers_agree_on_all_fp16_patterns(hip, mode):
+    """The 16-byte path quantises two fp16 patterns per instruction (quant_h2), the per-lane path (tails,
+    unaligned buffers) one (quant_h): all 65 536 patterns, with and without a scale, through both -- the same
+    bits, and the oracle's (stochastic modes: the same Philox stream, so the noise is the same too)."""
+    fmt, rm = hip.parse_mode(mode)
+    g = npz("luts.npz")
+    x = g["input_bits"].view(np.float32)
+    pad = torch.zeros(x.size + 1, dtype=torch.float32, device=DEV)
+    pad[1:] = torch.from_numpy(x).to(DEV)
+    src_unaligned = pad[1:]
+    assert src_unaligned.data_ptr() % 16 != 0
+    for s in (1.0, 0.37, 116.894):
+        packed = gpu_cast(hip, x, mode, scale=s, seed=9, offset=5)
+        dst = torch.empty(x.size + 1, dtype=torch.float32, device=DEV)[1:]
+        hip.cast_(src_unaligned, dst, fmt, rm, scale=s, seed=9, offset=5)
+        torch.cuda.synchronize()
+        want = orc.cast(x, mode, scale=s, seed=9, offset=5)
+        assert_bits_equal(packed, want, "%s packed scale=%r" % (mode, s))
+        assert_bits_equal(dst.cpu().numpy(), want, "%s per-lane scale=%r" % (mode, s))
+        if s == 1.0 and mode in g.files:
+            assert_bits_equal(packed, g[mode], mode + " vs reference LUT")
+
+
 @pytest.mark.parametrize("mode", DET_MODES)
 def test_rawbits_vs_reference(hip, mode):
     g = npz("rawbits.npz")
