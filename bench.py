@@ -108,6 +108,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip per-mode table and cpu baseline")
     args = ap.parse_args()
 
+    if os.environ.get("FPEMU_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["FPEMU_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -138,6 +142,16 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def all_reduce_max(t):
+        """RCCL reduces the device tensor in stream order.  The gloo rehearsal (ranks sharing one GPU) stages
+        through the host: gloo's own CUDA path hangs on back-to-back calls in that set-up."""
+        if backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            t.copy_(h)
+
     # Clock spin-up, untimed, ahead of the W warmup steps: the first ~40 launches after an idle GPU run 2-5 %
     # slower (tools/rampup.py: launches 0-19 include the cold launch, 20-39 6.59 TB/s, from 40 on 6.72-6.74),
     # and W is the driver's to choose.
@@ -162,7 +176,7 @@ def main():
     ms = (t1 - t0) * 1e3 / args.steps
     if world > 1:
         t = torch.tensor([ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_max(t)
         ms = float(t.item())
     value = world * n / (ms * 1e-3)
 
@@ -193,7 +207,7 @@ def main():
             ws.zero_()
             hip.amax_(x, ws)
             if world > 1:
-                dist.all_reduce(ws, op=dist.ReduceOp.MAX)
+                all_reduce_max(ws)
             hip.cast_scaled_(x, y, fmt, rm, ws, 448.0, clamp=True, seed=1, offset=0, elem_base=rank * n)
 
         for _ in range(3):
