@@ -16,12 +16,18 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 os.makedirs("profiles", exist_ok=True)
 
 
+def newest(pattern):
+    """gpurun merges each call's files into gpurun_out/ without removing older ones: take the latest."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 def short(name):
     name = name.replace("(anonymous namespace)::", "")
     return name if len(name) < 100 else name[:97] + "..."
 
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 rows = []
 if stats:
     for r in csv.DictReader(open(stats[0])):
@@ -34,7 +40,7 @@ with open("profiles/%s_kernel_stats.md" % tag, "w") as f:
         f.write("| `%s` | %d | %.1f | %.1f | %.1f | %.2f |\n" % (r["kernel"], r["calls"], r["avg_ns"] / 1e3,
                                                                 r["min_ns"] / 1e3, r["max_ns"] / 1e3, r["pct"]))
 
-gstats = glob.glob(os.path.join(src, "gemm_stats", "*", "*_kernel_stats.csv"))
+gstats = newest(os.path.join(src, "gemm_stats", "*", "*_kernel_stats.csv"))
 if gstats:
     with open("profiles/%s_gemm_kernel_stats.md" % tag, "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python3 tools/gemm_bench.py 8192x8192x8192 nn\n\n")
@@ -50,7 +56,7 @@ if gstats:
 
 pmc = {}
 for which, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    files = glob.glob(os.path.join(src, which, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(src, which, "*", "*_counter_collection.csv"))
     if not files:
         continue
     vals = {}
