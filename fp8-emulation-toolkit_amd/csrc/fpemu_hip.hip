@@ -239,14 +239,111 @@ __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_
   }
 }
 
+// Which casts take cast_blocks_sr (below): stochastic modes on fp32 storage.  With 16-bit storage the stochastic
+// cast is ALU-bound either way (twice the elements and noise per byte) and measured no better by slot: fp16
+// 6.2 -> 5.8 TB/s, bf16 6.3 -> 6.4.
+constexpr bool sr_by_slot(int rm, int dt) { return rm == STOCHASTIC && dt == FPEMU_F32; }
+
+// cast_vector's noise source in the stochastic flat cast: the W words of the lane's Philox results that cover
+// one slot (byte range [slot * V * NB, (slot + 1) * V * NB) of the lane's draw).
+template <int FMT, int W>
+struct SlotNoise {
+  uint32_t w[W];
+  __device__ __forceinline__ uint32_t one(unsigned e) const {
+    const unsigned pos = e * noise_bytes<FMT>();  // compile-time after unrolling
+    return w[pos / 4u] >> ((pos % 4u) * 8u);      // consumers mask the bits they use
+  }
+  __device__ __forceinline__ uint32_t pair(unsigned e) const {  // e even, one noise byte per element
+    return __builtin_amdgcn_perm(0u, w[e / 4u], (e % 4u) == 0u ? 0x0C010C00u : 0x0C030C02u);
+  }
+};
+
+// Stochastic modes.  The noise layout ties one Philox call to the four slots of a lane (DESIGN.md "Stochastic
+// rounding"), but four vectors per lane stream 3-5 % slower than one (tools/sweep.hip, U4 vs U1: a wave that
+// alternates a load phase and a store phase keeps fewer requests in flight).  So a 256-thread workgroup owns
+// ONE superblock and wave w streams slot w -- one vector per lane, as in the deterministic cast -- while the
+// Philox results of the superblock's 64 lanes are drawn once (NCALLS waves draw one call each) and handed round
+// through 1-4 KiB of LDS.  The draw and its barrier sit under the HBM latency of the loads issued before them.
+template <int FMT, int RM, int DT, class ScaleSrc>
+__device__ __forceinline__ void cast_blocks_sr(const void *in_, void *out_, uint64_t nsb, uint64_t n,
+                                               const ScaleSrc &src, uint64_t seed, uint64_t offset,
+                                               uint64_t elem_base, unsigned blk, unsigned nblk) {
+  constexpr unsigned V = Storage<DT>::V;
+  constexpr unsigned NB = noise_bytes<FMT>();
+  constexpr uint64_t SB_ELEMS = (uint64_t)V * 64u * 4u;
+  constexpr int NCALLS = (int)(4u * V * NB / 16u);  // Philox calls per lane and superblock: 1, 2 or 4
+  constexpr int W = (int)(V * NB / 4u);             // words of the lane's draw per slot
+  static_assert(cast_block(STOCHASTIC, DT) == 256 && sr_by_slot(RM, DT), "one wave per slot");
+  __shared__ uint32_t draw[NCALLS * 4 * 64];        // [call][word][lane]
+
+  const unsigned lane = threadIdx.x & 63u, slot = threadIdx.x >> 6;
+  const u32x4 *in = reinterpret_cast<const u32x4 *>(in_);
+  u32x4 *out = reinterpret_cast<u32x4 *>(out_);
+
+  uint64_t sb = blk;  // uniform over the workgroup: the barriers below are reached by all four waves or none
+  bool have = sb < nsb;
+  u32x4 v;
+  if (have) v = __builtin_nontemporal_load(&in[sb * 256u + slot * 64u + lane]);
+
+  float scale, rcp;
+  src.resolve(scale, rcp);
+
+  const uint64_t sb_base = elem_base / SB_ELEMS;
+  while (have) {
+    if (slot < (unsigned)NCALLS) {  // wave-uniform
+      const uint64_t c = (((sb_base + sb) * 64u + lane) << 2) | (uint64_t)slot;
+      const Philox4 p = philox4x32_10(seed, c, offset);
+      draw[(slot * 4u + 0u) * 64u + lane] = p.x;
+      draw[(slot * 4u + 1u) * 64u + lane] = p.y;
+      draw[(slot * 4u + 2u) * 64u + lane] = p.z;
+      draw[(slot * 4u + 3u) * 64u + lane] = p.w;
+    }
+    __syncthreads();
+    SlotNoise<FMT, W> noise;
+#pragma unroll
+    for (int i = 0; i < W; i++) noise.w[i] = draw[(slot * (unsigned)W + (unsigned)i) * 64u + lane];
+    store_stream(&out[sb * 256u + slot * 64u + lane], cast_vector<FMT, RM, DT>(v, scale, rcp, noise));
+
+    sb += nblk;  // only grids capped by fpemu_set_max_blocks come round again
+    have = sb < nsb;
+    if (have) {
+      v = __builtin_nontemporal_load(&in[sb * 256u + slot * 64u + lane]);
+      __syncthreads();  // everyone has read this round's draw before the next one is written
+    }
+  }
+
+  using elem_t = typename Storage<DT>::elem;
+  const elem_t *ein = reinterpret_cast<const elem_t *>(in_);
+  elem_t *eout = reinterpret_cast<elem_t *>(out_);
+  const uint64_t tstride = (uint64_t)nblk * 256u;
+  for (uint64_t i = nsb * SB_ELEMS + (uint64_t)blk * 256u + threadIdx.x; i < n; i += tstride) {
+    const uint32_t rnd = rand_bits_elem<FMT, V>(seed, offset, elem_base + i);
+    if constexpr (DT == FPEMU_F32) {
+      eout[i] = cast_one<FMT, RM>(ein[i], scale, rcp, rnd);
+    } else {
+      eout[i] = (elem_t)store_elem16<DT>(cast_one<FMT, RM>(load_elem16<DT>(ein[i]), scale, rcp, rnd));
+    }
+  }
+}
+
+// Workgroups a buffer of nsb superblocks takes on the 16-byte path.
+inline uint64_t superblock_groups(uint64_t nsb, int rmode, int dtype) {
+  if (sr_by_slot(rmode, dtype)) return nsb;  // one workgroup per superblock
+  const uint64_t waves = (uint64_t)cast_block(rmode, dtype) / 64u;
+  return (nsb + waves - 1) / waves;     // one wave per superblock
+}
+
 // The first ten arguments are 14 dwords: the part of the kernarg segment gfx950 preloads into SGPRs.
 template <int FMT, int RM, int DT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void cast_kernel(const void *in_, void *out_, uint64_t nsb, uint64_t n,
                                                       float scale, float rcp, const uint32_t *amax_bits,
                                                       uint32_t npart, int clamp, CastParams::Rest rest) {
   const DeviceScale<BLOCK> src{scale, rcp, amax_bits, npart, clamp, &rest};
-  cast_blocks<FMT, RM, DT, BLOCK>(in_, out_, nsb, n, src, rest.seed, rest.offset, rest.elem_base, blockIdx.x,
-                           gridDim.x);
+  if constexpr (sr_by_slot(RM, DT))
+    cast_blocks_sr<FMT, RM, DT>(in_, out_, nsb, n, src, rest.seed, rest.offset, rest.elem_base, blockIdx.x, gridDim.x);
+  else
+    cast_blocks<FMT, RM, DT, BLOCK>(in_, out_, nsb, n, src, rest.seed, rest.offset, rest.elem_base, blockIdx.x,
+                                    gridDim.x);
 }
 
 // Multi-tensor cast: one launch for up to kMultiTensors buffers of the same storage type and mode (the
@@ -271,8 +368,12 @@ __global__ __launch_bounds__(cast_block(RM, DT)) void cast_multi_kernel(MultiTab
   unsigned t = 0;
   while (t + 1u < tab.count && blockIdx.x >= tab.blk_end[t]) t++;  // uniform: scalar loads and compares
   const unsigned first = t == 0u ? 0u : tab.blk_end[t - 1u];
-  cast_blocks<FMT, RM, DT, cast_block(RM, DT)>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], GivenScale{scale, rcp}, seed, offset + t, 0,
-                           blockIdx.x - first, tab.blk_end[t] - first);
+  if constexpr (sr_by_slot(RM, DT))
+    cast_blocks_sr<FMT, RM, DT>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], GivenScale{scale, rcp}, seed, offset + t, 0,
+                                blockIdx.x - first, tab.blk_end[t] - first);
+  else
+    cast_blocks<FMT, RM, DT, cast_block(RM, DT)>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], GivenScale{scale, rcp},
+                                                 seed, offset + t, 0, blockIdx.x - first, tab.blk_end[t] - first);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -431,8 +532,8 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
   const uint64_t nsb = vec_ok ? n / sb_elems : 0;
   const uint64_t tail = n - nsb * sb_elems;
   const unsigned kCastBlock = wide ? (unsigned)kBlock : (unsigned)cast_block(rmode, dtype);
-  const unsigned kCastWaves = kCastBlock / 64u;
-  uint64_t blocks = (nsb + kCastWaves - 1) / kCastWaves;
+  uint64_t blocks = superblock_groups(nsb, rmode, dtype);
+  if (wide && !sr_by_slot(rmode, dtype)) blocks = (nsb + kWavesPerBlock - 1) / kWavesPerBlock;
   const uint64_t tail_blocks = (tail + kCastBlock - 1) / kCastBlock;
   if (blocks < tail_blocks) blocks = tail_blocks;
   if (blocks > (uint64_t)max_blocks()) blocks = (uint64_t)max_blocks();
@@ -538,7 +639,7 @@ int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, i
   }
   const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 64u * (unsigned)slots_per_wave(rmode, dtype);
   const float rcp = (float)(1.0 / (double)scale);  // cpp:714
-  const unsigned kCastBlock = (unsigned)cast_block(rmode, dtype), kCastWaves = kCastBlock / 64u;
+  const unsigned kCastBlock = (unsigned)cast_block(rmode, dtype);
   uint64_t i = 0;
   while (i < count) {
     MultiTable tab;
@@ -551,7 +652,7 @@ int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, i
       const bool vec_ok = (((uintptr_t)t.in | (uintptr_t)t.out) % 16u) == 0;
       const uint64_t nsb = vec_ok ? t.n / sb_elems : 0;
       const uint64_t tail = t.n - nsb * sb_elems;
-      uint64_t b = (nsb + kCastWaves - 1) / kCastWaves;
+      uint64_t b = superblock_groups(nsb, rmode, dtype);
       const uint64_t tb = (tail + kCastBlock - 1) / kCastBlock;
       if (b < tb) b = tb;
       if (b > (uint64_t)max_blocks()) b = (uint64_t)max_blocks();
