@@ -33,7 +33,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 16;  // VALU kernel: 128 x 128 x 16 tiles
-constexpr int MBK = 32;                     // k-depth of the MFMA kernel's tiles (half the barriers)
+#ifndef FPEMU_GEMM_MBK
+#define FPEMU_GEMM_MBK 32
+#endif
+constexpr int MBK = FPEMU_GEMM_MBK;         // k-depth of the MFMA kernel's tiles (32: half the barriers of 16)
 constexpr int NT = 256;
 // LDS images are k-major, T[k][r], row stride ROWS + 4 floats (2-way instead of 4-way write conflicts;
 // a 2-way ds_write_b32 conflict is free)
@@ -282,8 +285,12 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 // M x N needs small tiles to spread over CUs).  v_mfma_f32_32x32x2_f32: lane l supplies
 // A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; D[reg]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 // ---------------------------------------------------------------------------------------------
+#ifndef FPEMU_GEMM_WAVES
+#define FPEMU_GEMM_WAVES 2
+#endif
 template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL, int TW>
-__global__ __launch_bounds__(NT) void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FPEMU_GEMM_WAVES)))
+void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
                                                        float alpha, float beta, int tiles_m, int tiles_n,
                                                        Batch bt) {
   constexpr int TB = 64 * TW;  // block tile edge

@@ -119,7 +119,10 @@ struct LaneNoise {  // cast_vector's noise source in the flat cast: slot `slot` 
 // 16-byte vectors per lane: 4 for stochastic modes (the noise layout's superblock); deterministic fp32
 // storage 1 (pure stream, measured fastest); deterministic 16-bit storage 2 (twice the ALU work per byte:
 // a second independent vector per lane hides it)
-constexpr int slots_per_wave(int rm, int dt) { return rm == STOCHASTIC ? 4 : (dt == FPEMU_F32 ? 1 : 2); }
+#ifndef FPEMU_CAST_U16
+#define FPEMU_CAST_U16 2
+#endif
+constexpr int slots_per_wave(int rm, int dt) { return rm == STOCHASTIC ? 4 : (dt == FPEMU_F32 ? 1 : FPEMU_CAST_U16); }
 
 // Scale sources of the streaming body.  resolve() runs once per thread AFTER the first superblock's
 // loads have been issued, so whatever it waits for (a device word, the per-block maxima, a barrier)
