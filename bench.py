@@ -228,6 +228,33 @@ def main():
             extras["fused_per_tensor"] = {"ms_per_step": round(f_avg, 5),
                                           "GB/s_per_gpu": round(12 * n / (f_avg * 1e-3) / 1e9, 1)}
 
+        # BASELINE configs[4], one rank's part: an 8 GiB fp32 shard (2^31 elements, past 32-bit indexing) of a
+        # world x 8 GiB tensor -- local amax, all-reduce(max) of the one word over RCCL, cast with the global scale
+        try:
+            big = 1 << 31
+            xb = torch.empty(big, device=dev)
+            for c in range(0, big, 1 << 28):
+                xb[c:c + (1 << 28)].normal_()
+            yb = torch.empty_like(xb)
+
+            def shard_step():
+                ws.zero_()
+                hip.amax_(xb, ws)
+                if world > 1:
+                    all_reduce_max(ws)
+                hip.cast_scaled_(xb, yb, fmt, rm, ws, 448.0, clamp=True, seed=1, offset=0, elem_base=rank * big)
+
+            shard_step()
+            b_avg, _ = time_launches(shard_step, 3)
+            extras["shard_8GiB_scaled"] = {"ms_per_step": round(b_avg, 4),
+                                           "GB/s_per_gpu": round(12 * big / (b_avg * 1e-3) / 1e9, 1),
+                                           "tensor_GiB": 8 * world,
+                                           "collective": "all_reduce(max) of 4 B" if world > 1 else "none"}
+            del xb, yb
+        except torch.cuda.OutOfMemoryError:
+            extras["shard_8GiB_scaled"] = "skipped: out of device memory"
+        torch.cuda.empty_cache()
+
         def inplace_step():
             hip.cast_(y, y, fmt, rm, scale=1.0)
 
