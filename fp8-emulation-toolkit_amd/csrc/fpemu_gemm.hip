@@ -22,6 +22,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "../../include/fpemu_hip.h"
 
 extern "C" void fpemu_set_error_(const char *msg);  // fpemu_hip.hip: thread-local error text
@@ -421,6 +423,223 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
   }
 }
 
+typedef void (*mfma_fn_t)(Operand, Operand, float *, int64_t, float, float, int, int, Batch);
+
+// ---------------------------------------------------------------------------------------------
+// Latency-bound chains: problems with few outputs and a long k (the conv weight update: K_out x C*R*S outputs,
+// each a chain over N*OH*OW products) cannot fill the chip with 32x32 accumulator tiles, and every wave then runs
+// ONE dependent MFMA chain: a 32x32x2 step retires 2 k per 64 cycles.  v_mfma_f32_16x16x4_f32 is a k-ascending
+// fmaf chain as well (tools/mfma_order.hip: bit-identical to the host's chain) and retires 4 k per 32 cycles:
+// a quarter of the latency per k, on four times as many waves.  32 x 32 block tiles, 4 waves in a 2 x 2 grid,
+// one 16x16 accumulator tile per wave; 128-deep k tiles (32 dependent steps per barrier).
+// Lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; D[reg]: row = 4*(l>>4) + reg, col = l&15.
+// ---------------------------------------------------------------------------------------------
+constexpr int SB = 32, SK = 128, SLD = SB + 4, SNV = SK * SB / (4 * NT);
+
+template <bool KCONT>
+__device__ __forceinline__ void small_coords(int h, int tid, int &r, int &k) {
+  if constexpr (KCONT) {  // thread -> (row, 4 consecutive k): 8 threads per row, 32 k per pass
+    r = tid >> 3;
+    k = h * 32 + (tid & 7) * 4;
+  } else {                // thread -> (k, 4 consecutive rows): 8 threads per k, 32 k per pass
+    k = h * 32 + (tid >> 3);
+    r = (tid & 7) * 4;
+  }
+}
+
+template <bool KCONT, bool FULL>
+__device__ __forceinline__ f32x4 small_load_one(const Operand &X, const float *base, int r0, int k0, int tid, int h) {
+  int r, k;
+  small_coords<KCONT>(h, tid, r, k);
+  r += r0;
+  k += k0;
+  const float *src = KCONT ? base + (int64_t)r * X.ld + k : base + (int64_t)k * X.ld + r;
+  if constexpr (FULL) return *reinterpret_cast<const f32x4 *>(src);
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  const bool in_outer = KCONT ? (r < X.R) : (k < X.K);
+  const int inner = KCONT ? k : r, inner_end = KCONT ? X.K : X.R;
+  if (in_outer) {
+    if (X.vec && inner + 3 < inner_end) {
+      t = *reinterpret_cast<const f32x4 *>(src);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (inner + c < inner_end) t[c] = src[c];
+    }
+  }
+  return t;
+}
+
+template <bool KCONT>
+__device__ __forceinline__ void small_store_one(float *T, int tid, int h, const f32x4 v) {
+  int r, k;
+  small_coords<KCONT>(h, tid, r, k);
+  if constexpr (KCONT) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) T[(k + c) * SLD + r] = v[c];
+  } else {
+    *reinterpret_cast<f32x4 *>(&T[k * SLD + r]) = v;
+  }
+}
+
+// Where the next tile to fetch lies (k segments: the conv weight update chains image after image).
+struct FetchCursor {
+  const float *a, *b;
+  int k0, idx, total, K;
+  int64_t ka, kb;
+  __device__ __forceinline__ bool more() const { return idx < total; }
+  __device__ __forceinline__ void advance() {
+    idx++;
+    k0 += SK;
+    if (k0 >= K) {
+      k0 = 0;
+      a += ka;
+      b += kb;
+    }
+  }
+};
+
+template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL>
+__global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, float *C, int64_t ldc,
+                                                         float alpha, float beta, int tiles_m, int tiles_n,
+                                                         Batch bt) {
+  A.p += (int64_t)blockIdx.y * bt.sa;
+  B.p += (int64_t)blockIdx.y * bt.sb;
+  C += (int64_t)blockIdx.y * bt.sc;
+  __shared__ __attribute__((aligned(16))) float As[2][SK * SLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][SK * SLD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int tm, tn;
+  tile_of_block(tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * SB, n0 = tn * SB;
+  const int wm = (w >> 1) * 16, wn = (w & 1) * 16;
+  const int li = lane & 15, lk = lane >> 4;
+  const int K = A.K, M = A.R, N = B.R;
+  const int col = n0 + wn + li;
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (CHAIN) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = m0 + wm + 4 * lk + r;
+      if (row < M && col < N) acc[r] = C[(int64_t)row * ldc + col];
+    }
+  }
+
+  // A wave's MFMAs form ONE dependent chain (~40 cycles a step), and a wave issues in order: whatever else it
+  // has to do -- LDS reads of the next fragments, the next tile's LDS stores, the global loads of the tile after
+  // that -- is cut into slices and placed BETWEEN the chain's steps, where the issue slot would idle anyway.
+  // Tiles are fetched two ahead of the one being multiplied (two register stages, stage = tile parity) and
+  // stored into LDS a tile and a half later: a tile takes ~1300 cycles, a global load up to ~2000.
+  const int kt = (K + SK - 1) / SK, total = kt * bt.nseg;
+  FetchCursor cur{A.p, B.p, 0, 0, total, K, bt.ka, bt.kb};
+  f32x4 ra[2][SNV], rb[2][SNV];
+#pragma unroll
+  for (int sgi = 0; sgi < 2; sgi++) {  // tiles 0 and 1
+    if (cur.more()) {
+#pragma unroll
+      for (int h = 0; h < SNV; h++) {
+        ra[sgi][h] = small_load_one<A_KCONT, FULL>(A, cur.a, m0, cur.k0, tid, h);
+        rb[sgi][h] = small_load_one<B_KCONT, FULL>(B, cur.b, n0, cur.k0, tid, h);
+      }
+      cur.advance();
+    }
+  }
+  if (total > 0) {
+#pragma unroll
+    for (int h = 0; h < SNV; h++) {
+      small_store_one<A_KCONT>(As[0], tid, h, ra[0][h]);
+      small_store_one<B_KCONT>(Bs[0], tid, h, rb[0][h]);
+    }
+  }
+  __syncthreads();
+
+  constexpr int Q = SK / 16;  // MFMA steps per quarter of a tile
+  static_assert(Q == 2 * SNV, "one LDS-store slice and every other step one global-load slice per chain step");
+  const int aoff = lk * SLD + wm + li, boff = lk * SLD + wn + li;
+  // Tile t = it + PAR, LDS buffer PAR, in four quarters of 8 chain steps; after each step one slice of other work:
+  //   q0, q1  fragments of the next quarter; the global loads of tile t+2 into register stage PAR
+  //   q2      fragments of q3; tile t+1 (fetched a tile and a half ago into stage PAR^1) into LDS buffer PAR^1
+  //   -- the tile's ONE barrier: every wave holds its last fragments of buffer PAR and has stored its share of
+  //      buffer PAR^1 --
+  //   q3      the first fragments of tile t+1 from buffer PAR^1
+  // so no LDS latency is exposed at the barrier, and the next tile's chain continues without a gap.
+  // STEADY: the store and the fetch both happen (known at compile time: no branches inside the chain, so the
+  // compiler's waits stay exact); the last tiles of a chain take the form with run-time flags.
+  float fa[2][Q], fb[2][Q];
+  if (total > 0) {
+#pragma unroll
+    for (int st = 0; st < Q; st++) {
+      fa[0][st] = As[0][aoff + st * 4 * SLD];
+      fb[0][st] = Bs[0][boff + st * 4 * SLD];
+    }
+  }
+  auto tile_body = [&](auto par_c, auto steady_c, bool store_rt, bool fetch_rt) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const bool store_next = STEADY || store_rt, fetch_next = STEADY || fetch_rt;
+    const float *as = As[PAR] + aoff, *bs = Bs[PAR] + boff;
+    const float *an = As[PAR ^ 1] + aoff, *bn = Bs[PAR ^ 1] + boff;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = q & 1;
+#pragma unroll
+      for (int st = 0; st < Q; st++) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][st], fb[c][st], acc, 0, 0, 0);
+        if (q + 1 < 4) {  // fragments of the next quarter
+          fa[c ^ 1][st] = as[((q + 1) * Q + st) * 4 * SLD];
+          fb[c ^ 1][st] = bs[((q + 1) * Q + st) * 4 * SLD];
+        } else if (store_next) {  // first fragments of the next tile (its buffer is complete: the barrier is behind us)
+          fa[c ^ 1][st] = an[st * 4 * SLD];
+          fb[c ^ 1][st] = bn[st * 4 * SLD];
+        }
+        if (q == 2 && store_next) {  // one vector of the next tile into the other LDS buffer
+          if (st & 1) small_store_one<B_KCONT>(Bs[PAR ^ 1], tid, st >> 1, rb[PAR ^ 1][st >> 1]);
+          else small_store_one<A_KCONT>(As[PAR ^ 1], tid, st >> 1, ra[PAR ^ 1][st >> 1]);
+        }
+        if (q < 2 && fetch_next) {  // one vector of the tile after that into the register stage freed a tile ago
+          const int s16 = q * Q + st;
+          if ((s16 & 1) == 0) {
+            const int h = s16 >> 2;
+            if (s16 & 2) rb[PAR][h] = small_load_one<B_KCONT, FULL>(B, cur.b, n0, cur.k0, tid, h);
+            else ra[PAR][h] = small_load_one<A_KCONT, FULL>(A, cur.a, m0, cur.k0, tid, h);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (q == 2) __syncthreads();
+    }
+    if (fetch_next) cur.advance();
+  };
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+  int it = 0;
+  for (; it + 3 < total; it += 2) {  // tiles it and it+1 both store tile +1 and fetch tile +2
+    tile_body(c0{}, std::true_type{}, true, true);
+    tile_body(c1{}, std::true_type{}, true, true);
+  }
+  for (; it < total; it += 2) {
+    tile_body(c0{}, std::false_type{}, it + 1 < total, cur.more());
+    if (it + 1 >= total) break;
+    tile_body(c1{}, std::false_type{}, it + 2 < total, cur.more());
+  }
+
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = m0 + wm + 4 * lk + r;
+    if (FULL || (row < M && col < N)) {
+      float *dst = C + (int64_t)row * ldc + col;
+      if constexpr (CHAIN) *dst = acc[r];
+      else *dst = epilogue(*dst, acc[r], alpha, beta);
+    }
+  }
+}
+
+template <bool CHAIN, bool FULL> mfma_fn_t pick_mfma16(bool a_kcont, bool b_kcont) {
+  return a_kcont ? (b_kcont ? gemm_mfma16_kernel<true, true, CHAIN, FULL> : gemm_mfma16_kernel<true, false, CHAIN, FULL>)
+                 : (b_kcont ? gemm_mfma16_kernel<false, true, CHAIN, FULL> : gemm_mfma16_kernel<false, false, CHAIN, FULL>);
+}
+
 typedef void (*seqk_fn)(Operand, Operand, float *, int64_t, int, float, float, int, int, Batch);
 typedef void (*mfma_fn)(Operand, Operand, float *, int64_t, float, float, int, int, Batch);
 
@@ -468,19 +687,28 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   // Tile edge: 128 unless that leaves the chip mostly idle (fewer tiles than two per CU) -- a chain cannot
   // be split along k, so small M x N problems get 64 x 64 tiles (MFMA kernel only).
   const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch;
-  const int tb = (variant == 1 && (t128 < 512 || M <= 64 || N <= 64)) ? 64 : 128;
+  const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64) * batch;
+  // fewer 64 x 64 tiles than CUs: the chains are latency-bound -> 32 x 32 tiles of 16x16x4 MFMAs (gemm_mfma16_kernel)
+  const int64_t t32 = ((M + 31) / 32) * ((N + 31) / 32) * batch;
+  const bool small = variant == 1 && t64 < 256 && t32 <= 320;  // up to ~1.25 waves per SIMD (measured: at 576 tiles
+                                                               // the 64 x 64 kernel is the faster one again)
+  const int tb = small ? SB : (variant == 1 && (t128 < 512 || M <= 64 || N <= 64)) ? 64 : 128;
   const int tiles_m = (int)((M + tb - 1) / tb), tiles_n = (int)((N + tb - 1) / tb);
   const int64_t nwg = (int64_t)tiles_m * tiles_n;
   if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "too many tiles");
   const float beta = 0.0f;  // simple_gemm.cpp:58
   // every tile whole and 16-byte loads everywhere: the kernels drop their bounds tests
-  const bool full = a.vec && b.vec && (M % tb == 0) && (N % tb == 0) && (K % (variant == 1 ? MBK : BK) == 0) && K > 0;
+  const bool full = a.vec && b.vec && (M % tb == 0) && (N % tb == 0) && (K % (small ? SK : variant == 1 ? MBK : BK) == 0) && K > 0;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)nwg, (unsigned)batch);
   if (variant == 0) {
     seqk_fn fn = chain ? (full ? pick_seqk<true, true>(a_kcont, b_kcont) : pick_seqk<true, false>(a_kcont, b_kcont))
                        : (full ? pick_seqk<false, true>(a_kcont, b_kcont) : pick_seqk<false, false>(a_kcont, b_kcont));
     hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, c_vec, alpha, beta, tiles_m, tiles_n, bt);
+  } else if (small) {
+    mfma_fn fn = chain ? (full ? pick_mfma16<true, true>(a_kcont, b_kcont) : pick_mfma16<true, false>(a_kcont, b_kcont))
+                       : (full ? pick_mfma16<false, true>(a_kcont, b_kcont) : pick_mfma16<false, false>(a_kcont, b_kcont));
+    hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);
   } else if (variant == 1) {
     mfma_fn fn = tb == 64 ? pick_mfma_tw<1>(chain, full, a_kcont, b_kcont) : pick_mfma_tw<2>(chain, full, a_kcont, b_kcont);
     hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);

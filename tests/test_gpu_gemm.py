@@ -45,6 +45,9 @@ def test_gemm_vs_reference_fixture(hip, bname, variant, fused):
 @pytest.mark.parametrize("bname,variant,fused", VARIANTS)
 @pytest.mark.parametrize("shape", [(1, 1, 1), (7, 5, 3), (128, 128, 16), (129, 127, 17), (256, 384, 512),
                                    (300, 200, 1000), (64, 1024, 33), (1000, 8, 2048),
+                                   # few outputs, long k: the 16x16x4 chain kernel, odd / even tile counts,
+                                   # whole tiles and ragged ones (steady loop + every tail form)
+                                   (96, 160, 1664), (50, 70, 1500), (32, 32, 640), (33, 31, 129),
                                    (2950, 2944, 70), (2944, 2944, 64)])   # >= 512 tiles: the 128 x 128 kernels
 @pytest.mark.parametrize("at,bt", [(False, False), (True, False), (False, True), (True, True)])
 def test_gemm_vs_oracle(hip, bname, variant, fused, shape, at, bt):
