@@ -14,6 +14,8 @@
 // gemm_mfma_kernel   the fmaf chain, on v_mfma_f32_32x32x2_f32 (k-ordered, one rounding per step; bit-
 //                    exact against the reference's FMA build).  128x128x16 tiles, 4 waves, each a 64x64
 //                    quadrant as 2x2 MFMA tiles.  Roofline: fp32 MFMA, 157 TFLOP/s.
+// gemm_mfma16_kernel the same chain on v_mfma_f32_16x16x4_f32 for latency-bound problems (few outputs, long k:
+//                    the conv weight update): a quarter of the per-k latency on four times as many waves.
 // gemm_seqk_kernel   separate roundings: LDS-tiled VALU kernel, v_mul_f32 + v_add_f32 per step
 //                    (-ffp-contract=off), 8x8 outputs per lane, register prefetch of the next tile,
 //                    XCD-aware tile order.  Bit-exact against the reference's no-FMA build.  Roofline:

@@ -8,15 +8,18 @@
 //   fpemu_common_function           mpemu/pytquant/cpp/fpemu_impl.cpp:1866-2009
 // (one element per thread, 4-byte accesses, hipDeviceSynchronize per call, racy global RNG).
 //
-// Memory layout: buffers are flat and contiguous.  A wavefront covers one "superblock" =
-// U slots x 64 lanes x 16 B; lane L of the wave touches the U 16-byte vectors {slot*64 + L}, so
-// every load/store instruction of a wave is one fully coalesced 1 KiB segment.  Deterministic
-// modes use U = 1 (one vector per lane, one superblock per wave, no loop: the grid IS the
-// tensor -- measured fastest on MI355X, tools/sweep.hip); stochastic modes use U = 4 so that one
-// Philox4x32 call per lane (16 random bytes) feeds its 16 elements.  Loads are non-temporal
-// (read once); stores carry "sc1 nt" (streaming write-through): +2 % over nt stores, measured.
-// Elements past the last whole superblock (and whole buffers whose pointers are not 16-byte
-// aligned) go through a 4-byte-per-lane path in the same launch.
+// Memory layout: buffers are flat and contiguous.  A "superblock" = U slots x 64 lanes x 16 B; lane L touches
+// the U 16-byte vectors {slot*64 + L}, so every load/store instruction of a wave is one fully coalesced 1 KiB
+// segment.  Deterministic modes: U = 1, one superblock per wave, no loop -- the grid IS the tensor (measured
+// fastest on MI355X, tools/sweep.hip) -- in 128-thread workgroups; the data load is the first thing a wave
+// does (kernarg preload puts its address in SGPRs at launch; a device-side scale is resolved after the load
+// is in flight).  Stochastic modes: the noise layout's superblock has U = 4 (one Philox4x32 call per lane =
+// 16 random bytes = its 16 elements); with fp32 storage a 256-thread workgroup owns one superblock, one slot
+// per wave, and shares the Philox draw through LDS (cast_blocks_sr); with 16-bit storage a wave keeps all four
+// slots.  Loads are non-temporal (read once); stores carry "sc1 nt" (streaming write-through): +2 % over nt
+// stores, measured.  E5M2 / E4M3 / E3M4 under RTZ / RNE / STOCHASTIC quantise two elements per instruction
+// (fpemu_device.hpp, quant_h2).  Elements past the last whole superblock (and whole buffers whose pointers are
+// not 16-byte aligned) go through a 4-byte-per-lane path in the same launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
