@@ -70,3 +70,42 @@ def test_random_cases_vs_oracle(hip):
                 assert np.array_equal(got[~nan], want[~nan]), what
         finally:
             hip.lib().fpemu_set_max_blocks(0)
+
+
+def test_random_rows_and_blocks_vs_oracle(hip):
+    """Per-row (per-channel, clamped or not) and block-norm quantisation over random shapes -- every team shape of
+    the rows kernels (sub-vector, lane groups of 1..256 lanes with 1..8 held vectors, two-pass wave / block
+    teams, unaligned rows) -- against the oracle's loop of per-row casts."""
+    from _util import FLT_MAX
+
+    rng = np.random.default_rng(7)
+    modes = ["E4M3_RNE", "E5M2_RNE", "E3M4_RNE", "E4M3_STOCHASTIC", "E5M2_STOCHASTIC", "E4M3_RTZ", "E5M2_RNAZ"]
+    col_choices = [1, 2, 3, 4, 7, 8, 16, 20, 64, 100, 256, 260, 768, 1000, 1024, 1028, 4096, 8192, 8196, 12288, 20000]
+    for case in range(120):
+        mode = modes[int(rng.integers(len(modes)))]
+        fmt, rm = hip.parse_mode(mode)
+        cols = int(rng.choice(col_choices))
+        rows = int(rng.integers(1, max(2, min(600, (1 << 21) // cols))))
+        kind = ("clamp", "noclamp", "blocknorm")[int(rng.integers(3))]
+        if kind == "blocknorm" and mode in ("E4M3_RTZ",):
+            kind = "clamp"
+        x = (rng.standard_normal((rows, cols)) * np.exp(rng.standard_normal((rows, 1)) * 5)).astype(np.float32)
+        if rows > 1:
+            x[rows // 2] = 0.0
+        t = torch.from_numpy(x).to(DEV)
+        o = torch.empty_like(t)
+        hip.set_rng_state((31, 4000))
+        what = "rows case %d: %s %s %dx%d" % (case, mode, kind, rows, cols)
+        if kind == "blocknorm":
+            hip.quantize_blocks_(t, o, cols, fmt, rm)
+            got = o.cpu().numpy()
+            want = orc.cast_blocknorm(x.reshape(-1), mode, cols, seed=31, offset=4000).reshape(rows, cols)
+            assert_bits_equal(got, want, what, nan_payload_ok=True)
+        else:
+            fmax = FLT_MAX[mode.split("_")[0]]
+            hip.quantize_rows_(t, o, rows, fmt, rm, fmax, clamp=(kind == "clamp"))
+            got = o.cpu().numpy()
+            for r in sorted(set([0, rows - 1, rows // 2] + [int(v) for v in rng.integers(0, rows, size=6)])):
+                s = orc.scale_from_amax(orc.amax(x[r]), fmax, clamp=(kind == "clamp"))
+                want = orc.cast(x[r], mode, scale=s, seed=31, offset=4000 + r)
+                assert_bits_equal(got[r], want, what + " row %d" % r, nan_payload_ok=True)
