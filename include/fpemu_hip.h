@@ -144,8 +144,9 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
 /* fpemu_quantize_per_tensor with a scratch workspace instead of the single amax word.  Above the
  * one-workgroup size the library then runs TWO launches -- up to 256 per-block maxima into ws[1..], and
  * the cast, whose blocks reduce those maxima themselves -- instead of three (zero the word, atomic amax,
- * cast): no atomics and no word to initialise; measured faster or equal at every size (11.6 -> 8.8 us
- * at 3 MiB, 56 -> 36 us at 64 MiB, 0.550 -> 0.546 ms at 1 GiB).  Results are identical.
+ * cast): no atomics and no word to initialise; measured faster up to 512 MiB (11.6 -> 8.6 us at 3 MiB,
+ * 53 -> 34 us at 64 MiB, 0.259 -> 0.246 ms at 512 MiB).  Tensors above 768 MiB take the single-word
+ * sequence here as well (0.489 vs 0.503 ms at 1 GiB).  Results are identical.
  * ws: ws_words >= 1 device words (257 for the full effect), contents need not be initialised; in stream
  * order after the call ws[0] holds the amax bit pattern.  One workspace per stream (calls on different
  * streams must not share one). */
