@@ -37,6 +37,7 @@ extern "C" void fpemu_set_error_(const char *msg);
 namespace {
 
 constexpr int NT = 256;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Geo {
   int64_t N, C, H, W, K, R, S, stride, pad, OH, OW, CB, KB;
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(NT) void pack_w_bp(const float *__restrict__ w, flo
 // cols[n][(cb, kj, ki, c2)][(oj, oi)] = x[n0 + n][cb*CB + c2][oj*s + kj - pad][oi*s + ki - pad], 0 outside.
 // One (image, kk) row of the gathered matrix per blockIdx.y (decoded once, scalar), threads along the
 // pixels: coalesced stores, row-local loads, 32-bit index arithmetic per element.
+template <bool vec4>
 __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float *__restrict__ cols, Geo g,
                                               int64_t nrows) {
   const int P = (int)(g.OH * g.OW), OW = (int)g.OW, H = (int)g.H, W = (int)g.W, st = (int)g.stride;
@@ -104,6 +106,20 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
     const float *src = x + (n * g.C + cb * g.CB + c2) * (int64_t)H * W;
     float *dst = cols + row * P;
     const int y0 = kj - (int)g.pad, x0 = ki - (int)g.pad;
+    if constexpr (vec4) {  // four pixels per lane, one 16-byte store (rows are whole vectors and 16-byte aligned)
+      for (int p = (blockIdx.x * NT + threadIdx.x) * 4; p < P; p += gridDim.x * NT * 4) {
+        f32x4 o;
+        int oj = p / OW, oi = p - oj * OW;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int y = oj * st + y0, xx = oi * st + x0;
+          o[e] = ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) ? src[y * W + xx] : 0.f;
+          if (++oi == OW) { oi = 0; oj++; }
+        }
+        *reinterpret_cast<f32x4 *>(dst + p) = o;
+      }
+      continue;
+    }
     for (int p = blockIdx.x * NT + threadIdx.x; p < P; p += gridDim.x * NT) {
       const int oj = p / OW, oi = p - oj * OW;
       const int y = oj * st + y0, xx = oi * st + x0;
@@ -117,6 +133,7 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
 // colsb[n][(ob, tj, ti, o2)][(ih, iw)] = gout[n][ob*KB + o2][oj][oi] with kj = R-1-tj, ki = ti,
 // oj = (ih + pad - kj)/s, oi = (iw + pad - ki)/s when those divide and are in range, else 0.
 // Same decomposition: one gathered row per blockIdx.y, threads along the input pixels.
+template <bool vec4>
 __global__ __launch_bounds__(NT) void cols_bp(const float *__restrict__ go, float *__restrict__ cols, Geo g,
                                               int64_t nrows) {
   const int HW = (int)(g.H * g.W), W = (int)g.W, OH = (int)g.OH, OW = (int)g.OW, st = (int)g.stride;
@@ -131,6 +148,25 @@ __global__ __launch_bounds__(NT) void cols_bp(const float *__restrict__ go, floa
     const float *src = go + (n * g.K + ob * g.KB + o2) * (int64_t)OH * OW;
     float *dst = cols + row * HW;
     const int y0 = (int)g.pad - ((int)g.R - 1 - tj), x0 = (int)g.pad - ti;
+    if constexpr (vec4) {  // four input pixels per lane, one 16-byte store
+      for (int pix = (blockIdx.x * NT + threadIdx.x) * 4; pix < HW; pix += gridDim.x * NT * 4) {
+        f32x4 o;
+        int ih = pix / W, iw = pix - ih * W;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int dy = ih + y0, dx = iw + x0;
+          float v = 0.f;
+          if (dy >= 0 && dx >= 0) {
+            const int oj = dy / st, oi = dx / st;
+            if (oj * st == dy && oi * st == dx && oj < OH && oi < OW) v = src[oj * OW + oi];
+          }
+          o[e] = v;
+          if (++iw == W) { iw = 0; ih++; }
+        }
+        *reinterpret_cast<f32x4 *>(dst + pix) = o;
+      }
+      continue;
+    }
     for (int pix = blockIdx.x * NT + threadIdx.x; pix < HW; pix += gridDim.x * NT) {
       const int ih = pix / W, iw = pix - ih * W;
       const int dy = ih + y0, dx = iw + x0;
@@ -266,7 +302,8 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   CHECK_LAUNCH(who);
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL(cols_fp, gather_grid(P, nb * crs), dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs);
+    hipLaunchKernelGGL((P % 4 == 0 && ((uintptr_t)cols % 16u) == 0) ? cols_fp<true> : cols_fp<false>, gather_grid(P, nb * crs),
+                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_f32(out + n0 * K * P, Wm, cols, K, P, crs, crs, P, P, 0, 0, variant, nb, 0, crs * P,
                               K * P, 1, 0, 0, stream);
@@ -298,7 +335,8 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
   CHECK_LAUNCH(who);
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL(cols_bp, gather_grid(HW, nb * krs), dim3(NT), 0, s, gout + n0 * K * P, cols, g, nb * krs);
+    hipLaunchKernelGGL((HW % 4 == 0 && ((uintptr_t)cols % 16u) == 0) ? cols_bp<true> : cols_bp<false>, gather_grid(HW, nb * krs),
+                       dim3(NT), 0, s, gout + n0 * K * P, cols, g, nb * krs);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_f32(gin + n0 * C * HW, Wm, cols, C, HW, krs, krs, HW, HW, 0, 0, variant, nb, 0, krs * HW,
                               C * HW, 1, 0, 0, stream);
@@ -328,7 +366,8 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
   CHECK_LAUNCH(who);
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL(cols_fp, gather_grid(P, nb * crs), dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs);
+    hipLaunchKernelGGL((P % 4 == 0 && ((uintptr_t)cols % 16u) == 0) ? cols_fp<true> : cols_fp<false>, gather_grid(P, nb * crs),
+                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs);
     CHECK_LAUNCH(who);
     // one chain across the chunk's images in ONE launch: k segments = images (chunks follow in order)
     rc = fpemu_gemm_chain_f32(Gm, gout + n0 * K * P, cols, K, crs, P, P, P, crs, 0, 1, variant, 1, 0, 0, 0, nb,
