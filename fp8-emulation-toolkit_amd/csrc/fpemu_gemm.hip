@@ -289,6 +289,9 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 // M x N needs small tiles to spread over CUs).  v_mfma_f32_32x32x2_f32: lane l supplies
 // A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; D[reg]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 // ---------------------------------------------------------------------------------------------
+#ifndef FPEMU_GEMM_PIPE
+#define FPEMU_GEMM_PIPE 1
+#endif
 #ifndef FPEMU_GEMM_WAVES
 #define FPEMU_GEMM_WAVES 2
 #endif
@@ -339,6 +342,16 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
   int cur = 0;
   const int kt = (K + MBK - 1) / MBK, total = kt * bt.nseg;
   int nk0 = 0;  // k offset of the tile being prefetched
+#if FPEMU_GEMM_PIPE
+  float fa[8][TW], fb[8][TW];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {  // fragments of the first tile's first AHEAD steps
+#pragma unroll
+    for (int i = 0; i < TW; i++) fa[t][i] = As[0][lk * LDT + wm + li + t * 2 * LDT + i * 32];
+#pragma unroll
+    for (int j = 0; j < TW; j++) fb[t][j] = Bs[0][lk * LDT + wn + li + t * 2 * LDT + j * 32];
+  }
+#endif
   for (int it = 0; it < total; it++) {
     const bool more = it + 1 < total;
     if (more) {
@@ -351,6 +364,42 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
       tile_load<A_KCONT, FULL, MBK, TB>(A, abase, m0, nk0, tid, pa);
       tile_load<B_KCONT, FULL, MBK, TB>(B, bbase, n0, nk0, tid, pb);
     }
+#if FPEMU_GEMM_PIPE
+    // Fragments are read AHEAD steps before the MFMAs that consume them, into a ring of RING register sets.
+    // The iteration's one barrier sits after step NSTEP - AHEAD - 1: by then every wave has issued its last read
+    // of this LDS buffer (the fragments of the last AHEAD steps are in registers) and has stored its share of
+    // the next tile into the other buffer, so the last AHEAD steps already read the NEXT tile's first fragments
+    // and the MFMA stream crosses the iteration boundary without a barrier or an exposed LDS round trip.
+    // (Past the last tile those reads fetch unused values from the other buffer: no branch in the stream.)
+    constexpr int NSTEP = MBK / 2, AHEAD = 4, RING = 8;
+    static_assert(NSTEP % RING == 0 && AHEAD < RING, "ring slots are compile-time across iterations");
+    const float *as = As[cur] + lk * LDT + wm + li, *bs = Bs[cur] + lk * LDT + wn + li;
+    const float *an = As[cur ^ 1] + lk * LDT + wm + li, *bn = Bs[cur ^ 1] + lk * LDT + wn + li;
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++) {
+      const int t = st + AHEAD, slot = t % RING;
+      const float *sa = t < NSTEP ? as : an, *sb = t < NSTEP ? bs : bn;
+#pragma unroll
+      for (int i = 0; i < TW; i++) fa[slot][i] = sa[(t % NSTEP) * 2 * LDT + i * 32];
+#pragma unroll
+      for (int j = 0; j < TW; j++) fb[slot][j] = sb[(t % NSTEP) * 2 * LDT + j * 32];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TW; i++)
+#pragma unroll
+        for (int j = 0; j < TW; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st % RING][i], fb[st % RING][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (st == NSTEP - AHEAD - 3 && more) {
+        tile_store<A_KCONT, MBK, TB>(As[cur ^ 1], tid, pa);
+        tile_store<B_KCONT, MBK, TB>(Bs[cur ^ 1], tid, pb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (st == NSTEP - AHEAD - 1) __syncthreads();
+    }
+    cur ^= 1;
+  }
+#else
     const float *as = As[cur] + lk * LDT + wm + li, *bs = Bs[cur] + lk * LDT + wn + li;
     // operand fragments one k-pair ahead of the MFMAs that consume them (register double buffer), so the
     // LDS latency of step s+1 runs under the MFMAs of step s
@@ -387,6 +436,8 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
     __syncthreads();
     cur ^= 1;
   }
+
+#endif
 
   const int M = A.R, N = B.R;
   if constexpr (CHAIN) {
