@@ -114,6 +114,25 @@ __device__ __forceinline__ void tile_load(const Operand &X, const float *base, i
   }
 }
 
+// FULL tiles: the address of vector h is (per-thread pointer computed once) + (uniform offset of the tile), one
+// 64-bit add per load.  Left to the generic form above, every iteration redoes the row * ld products in 64-bit
+// VALU arithmetic (quarter-rate multiplies): ~300 issue cycles per tile ahead of the loads, in the MFMA stream.
+template <bool KCONT, int TBK, int ROWS>
+__device__ __forceinline__ void tile_ptrs(const Operand &X, int r0, int tid, const float *(&tp)[TBK * ROWS / 1024]) {
+#pragma unroll
+  for (int h = 0; h < TBK * ROWS / 1024; h++) {
+    int r, k;
+    tile_coords<KCONT, TBK, ROWS>(h, tid, r, k);
+    r += r0;
+    tp[h] = KCONT ? X.p + (int64_t)r * X.ld + k : X.p + (int64_t)k * X.ld + r;
+  }
+}
+template <int NVEC>
+__device__ __forceinline__ void tile_load_ptrs(const float *const (&tp)[NVEC], int64_t uoff, f32x4 (&v)[NVEC]) {
+#pragma unroll
+  for (int h = 0; h < NVEC; h++) v[h] = *reinterpret_cast<const f32x4 *>(tp[h] + uoff);
+}
+
 // Registers -> LDS image T[k][r].
 template <bool KCONT, int TBK, int ROWS>
 __device__ __forceinline__ void tile_store(float *T, int tid, const f32x4 (&v)[TBK * ROWS / 1024]) {
@@ -128,6 +147,19 @@ __device__ __forceinline__ void tile_store(float *T, int tid, const f32x4 (&v)[T
     } else {
       *reinterpret_cast<f32x4 *>(&T[k * LD + r]) = v[h];
     }
+  }
+}
+
+template <bool KCONT, int TBK, int ROWS>
+__device__ __forceinline__ void tile_store_one(float *T, int tid, int h, const f32x4 v) {
+  constexpr int LD = ldt<ROWS>();
+  int r, k;
+  tile_coords<KCONT, TBK, ROWS>(h, tid, r, k);
+  if constexpr (KCONT) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) T[(k + c) * LD + r] = v[c];
+  } else {
+    *reinterpret_cast<f32x4 *>(&T[k * LD + r]) = v;
   }
 }
 
@@ -289,6 +321,9 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 // M x N needs small tiles to spread over CUs).  v_mfma_f32_32x32x2_f32: lane l supplies
 // A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; D[reg]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 // ---------------------------------------------------------------------------------------------
+#ifndef FPEMU_GEMM_PTRS
+#define FPEMU_GEMM_PTRS 1
+#endif
 #ifndef FPEMU_GEMM_PIPE
 #define FPEMU_GEMM_PIPE 1
 #endif
@@ -333,6 +368,11 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
 
   f32x4 pa[NV], pb[NV];
   const float *abase = A.p, *bbase = B.p;
+  const float *tpa[NV], *tpb[NV];  // FULL: per-thread pointers of the vectors of tile (segment 0, k0 = 0)
+  if constexpr (FULL) {
+    tile_ptrs<A_KCONT, MBK, TB>(A, m0, tid, tpa);
+    tile_ptrs<B_KCONT, MBK, TB>(B, n0, tid, tpb);
+  }
   tile_load<A_KCONT, FULL, MBK, TB>(A, abase, m0, 0, tid, pa);
   tile_load<B_KCONT, FULL, MBK, TB>(B, bbase, n0, 0, tid, pb);
   tile_store<A_KCONT, MBK, TB>(As[0], tid, pa);
@@ -352,27 +392,35 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
     for (int j = 0; j < TW; j++) fb[t][j] = Bs[0][lk * LDT + wn + li + t * 2 * LDT + j * 32];
   }
 #endif
-  for (int it = 0; it < total; it++) {
-    const bool more = it + 1 < total;
-    if (more) {
+#if FPEMU_GEMM_PIPE
+  // Fragments are read AHEAD steps before the MFMAs that consume them, into a ring of RING register sets.
+  // The iteration's one barrier sits after step NSTEP - AHEAD - 1: by then every wave has issued its last read
+  // of this LDS buffer (the fragments of the last AHEAD steps are in registers) and has stored its share of
+  // the next tile into the other buffer, so the last AHEAD steps already read the NEXT tile's first fragments
+  // and the MFMA stream crosses the iteration boundary without a barrier or an exposed LDS round trip.
+  // (Past the last tile those reads fetch unused values from the other buffer: no branch in the stream.)
+  // The next tile's LDS stores go out one vector per step over the steps before the barrier (each waits only
+  // for its own global load).  MORE is a compile-time flag -- the last iteration is peeled -- so there is no
+  // branch inside the stream and the compiler's waits stay exact.
+  constexpr int NSTEP = MBK / 2, AHEAD = 4, RING = 8, S0 = NSTEP - AHEAD - 2 * NV;
+  static_assert(NSTEP % RING == 0 && AHEAD < RING && S0 >= 0, "ring slots are compile-time across iterations");
+  auto iter_body = [&](auto more_c) {
+    constexpr bool MORE = decltype(more_c)::value;
+    if constexpr (MORE) {
       nk0 += MBK;
       if (nk0 >= K) {  // next k segment
         nk0 = 0;
         abase += bt.ka;
         bbase += bt.kb;
       }
-      tile_load<A_KCONT, FULL, MBK, TB>(A, abase, m0, nk0, tid, pa);
-      tile_load<B_KCONT, FULL, MBK, TB>(B, bbase, n0, nk0, tid, pb);
+      if constexpr (FULL && FPEMU_GEMM_PTRS) {  // uniform offsets (scalar arithmetic), one 64-bit add per vector
+        tile_load_ptrs<NV>(tpa, (abase - A.p) + (A_KCONT ? (int64_t)nk0 : (int64_t)nk0 * A.ld), pa);
+        tile_load_ptrs<NV>(tpb, (bbase - B.p) + (B_KCONT ? (int64_t)nk0 : (int64_t)nk0 * B.ld), pb);
+      } else {
+        tile_load<A_KCONT, FULL, MBK, TB>(A, abase, m0, nk0, tid, pa);
+        tile_load<B_KCONT, FULL, MBK, TB>(B, bbase, n0, nk0, tid, pb);
+      }
     }
-#if FPEMU_GEMM_PIPE
-    // Fragments are read AHEAD steps before the MFMAs that consume them, into a ring of RING register sets.
-    // The iteration's one barrier sits after step NSTEP - AHEAD - 1: by then every wave has issued its last read
-    // of this LDS buffer (the fragments of the last AHEAD steps are in registers) and has stored its share of
-    // the next tile into the other buffer, so the last AHEAD steps already read the NEXT tile's first fragments
-    // and the MFMA stream crosses the iteration boundary without a barrier or an exposed LDS round trip.
-    // (Past the last tile those reads fetch unused values from the other buffer: no branch in the stream.)
-    constexpr int NSTEP = MBK / 2, AHEAD = 4, RING = 8;
-    static_assert(NSTEP % RING == 0 && AHEAD < RING, "ring slots are compile-time across iterations");
     const float *as = As[cur] + lk * LDT + wm + li, *bs = Bs[cur] + lk * LDT + wn + li;
     const float *an = As[cur ^ 1] + lk * LDT + wm + li, *bn = Bs[cur ^ 1] + lk * LDT + wn + li;
 #pragma unroll
@@ -390,16 +438,38 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
         for (int j = 0; j < TW; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st % RING][i], fb[st % RING][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (st == NSTEP - AHEAD - 3 && more) {
-        tile_store<A_KCONT, MBK, TB>(As[cur ^ 1], tid, pa);
-        tile_store<B_KCONT, MBK, TB>(Bs[cur ^ 1], tid, pb);
-        __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MORE) {
+        if (st >= S0 && st < S0 + 2 * NV) {
+          const int idx = st - S0;
+          if (idx & 1) tile_store_one<B_KCONT, MBK, TB>(Bs[cur ^ 1], tid, idx >> 1, pb[idx >> 1]);
+          else tile_store_one<A_KCONT, MBK, TB>(As[cur ^ 1], tid, idx >> 1, pa[idx >> 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if (st == NSTEP - AHEAD - 1) __syncthreads();
     }
     cur ^= 1;
-  }
+  };
+  for (int it = 0; it + 1 < total; it++) iter_body(std::true_type{});
+  if (total > 0) iter_body(std::false_type{});
 #else
+  for (int it = 0; it < total; it++) {
+    const bool more = it + 1 < total;
+    if (more) {
+      nk0 += MBK;
+      if (nk0 >= K) {  // next k segment
+        nk0 = 0;
+        abase += bt.ka;
+        bbase += bt.kb;
+      }
+      if constexpr (FULL && FPEMU_GEMM_PTRS) {  // uniform offsets (scalar arithmetic), one 64-bit add per vector
+        tile_load_ptrs<NV>(tpa, (abase - A.p) + (A_KCONT ? (int64_t)nk0 : (int64_t)nk0 * A.ld), pa);
+        tile_load_ptrs<NV>(tpb, (bbase - B.p) + (B_KCONT ? (int64_t)nk0 : (int64_t)nk0 * B.ld), pb);
+      } else {
+        tile_load<A_KCONT, FULL, MBK, TB>(A, abase, m0, nk0, tid, pa);
+        tile_load<B_KCONT, FULL, MBK, TB>(B, bbase, n0, nk0, tid, pb);
+      }
+    }
     const float *as = As[cur] + lk * LDT + wm + li, *bs = Bs[cur] + lk * LDT + wn + li;
     // operand fragments one k-pair ahead of the MFMAs that consume them (register double buffer), so the
     // LDS latency of step s+1 runs under the MFMAs of step s

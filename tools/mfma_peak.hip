@@ -1,0 +1,49 @@
+// tools/mfma_peak.hip -- what the fp32 MFMA pipe sustains with nothing else going on: 4 independent 32x32x2
+// accumulator chains per wave (the GEMM kernel's shape), W waves per SIMD, no memory traffic.
+//   hipcc -O3 --offload-arch=gfx950 -o tools/mfma_peak tools/mfma_peak.hip && tools/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void spin(float *out, int iters, float a0, float b0) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; i++)
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  float a = a0 + threadIdx.x, b = b0;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; i++)
+    for (int r = 0; r < 16; r++) s += acc[i][r];
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+int main() {
+  float *out;
+  CK(hipMalloc(&out, 4096));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int iters = 4000;
+  for (int wps = 1; wps <= 2; wps++) {           // waves per SIMD: blocks of 4 waves, wps blocks per CU
+    const int blocks = 256 * wps;
+    for (int rep = 0; rep < 3; rep++) {
+      CK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(spin, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f, 0.5f);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double flop = (double)blocks * 4 /*waves*/ * iters * 64.0 /*mfma*/ * 4096.0;
+      printf("%d wave(s) per SIMD: %.3f ms  %.1f TFLOP/s (fp32 MFMA 32x32x2, %d blocks)\n", wps, ms, flop / ms / 1e9, blocks);
+    }
+  }
+  return 0;
+}
