@@ -324,6 +324,9 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 #ifndef FPEMU_GEMM_PTRS
 #define FPEMU_GEMM_PTRS 1
 #endif
+#ifndef FPEMU_GEMM_AHEAD2
+#define FPEMU_GEMM_AHEAD2 1
+#endif
 #ifndef FPEMU_GEMM_PIPE
 #define FPEMU_GEMM_PIPE 1
 #endif
@@ -379,7 +382,7 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
   tile_store<B_KCONT, MBK, TB>(Bs[0], tid, pb);
   __syncthreads();
 
-  int cur = 0;
+  [[maybe_unused]] int cur = 0;
   const int kt = (K + MBK - 1) / MBK, total = kt * bt.nseg;
   int nk0 = 0;  // k offset of the tile being prefetched
 #if FPEMU_GEMM_PIPE
@@ -404,6 +407,79 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
   // branch inside the stream and the compiler's waits stay exact.
   constexpr int NSTEP = MBK / 2, AHEAD = 4, RING = 8, S0 = NSTEP - AHEAD - 2 * NV;
   static_assert(NSTEP % RING == 0 && AHEAD < RING && S0 >= 0, "ring slots are compile-time across iterations");
+#if FPEMU_GEMM_AHEAD2
+  // Tiles are fetched TWO ahead (register stage = tile parity): a global load gets a whole iteration plus the
+  // steps up to its store (> 5000 cycles) to land, instead of the 1000-2800 of a one-tile distance.
+  f32x4 qa[NV], qb[NV];  // stage 1 (stage 0 = pa / pb)
+  int fetched = 1;       // tiles fetched so far (tile 0 came through pa / pb in the prologue)
+  auto fetch = [&](f32x4 (&ra)[NV], f32x4 (&rb)[NV]) {
+    nk0 += MBK;
+    if (nk0 >= K) {  // next k segment
+      nk0 = 0;
+      abase += bt.ka;
+      bbase += bt.kb;
+    }
+    if constexpr (FULL && FPEMU_GEMM_PTRS) {
+      tile_load_ptrs<NV>(tpa, (abase - A.p) + (A_KCONT ? (int64_t)nk0 : (int64_t)nk0 * A.ld), ra);
+      tile_load_ptrs<NV>(tpb, (bbase - B.p) + (B_KCONT ? (int64_t)nk0 : (int64_t)nk0 * B.ld), rb);
+    } else {
+      tile_load<A_KCONT, FULL, MBK, TB>(A, abase, m0, nk0, tid, ra);
+      tile_load<B_KCONT, FULL, MBK, TB>(B, bbase, n0, nk0, tid, rb);
+    }
+    fetched++;
+  };
+  if (total > 1) fetch(qa, qb);  // tile 1 -> stage 1
+  // tile t = it + PAR is multiplied from LDS buffer PAR; tile t+1 sits in stage PAR^1 and goes into LDS buffer
+  // PAR^1 during this iteration; tile t+2 is fetched into stage PAR (whose tile t went into LDS an iteration ago)
+  auto iter_body = [&](auto par_c, auto steady_c, bool store_rt, bool fetch_rt) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const bool store_next = STEADY || store_rt, fetch_next = STEADY || fetch_rt;
+    f32x4(&sa_)[NV] = PAR ? pa : qa;  // stage PAR^1: the tile to store
+    f32x4(&sb_)[NV] = PAR ? pb : qb;
+    if (fetch_next) {
+      if constexpr (PAR) fetch(qa, qb);
+      else fetch(pa, pb);
+    }
+    const float *as = As[PAR] + lk * LDT + wm + li, *bs = Bs[PAR] + lk * LDT + wn + li;
+    const float *an = As[PAR ^ 1] + lk * LDT + wm + li, *bn = Bs[PAR ^ 1] + lk * LDT + wn + li;
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++) {
+      const int t = st + AHEAD, slot = t % RING;
+      const float *sa = t < NSTEP ? as : an, *sb = t < NSTEP ? bs : bn;
+#pragma unroll
+      for (int i = 0; i < TW; i++) fa[slot][i] = sa[(t % NSTEP) * 2 * LDT + i * 32];
+#pragma unroll
+      for (int j = 0; j < TW; j++) fb[slot][j] = sb[(t % NSTEP) * 2 * LDT + j * 32];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TW; i++)
+#pragma unroll
+        for (int j = 0; j < TW; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st % RING][i], fb[st % RING][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (st >= S0 && st < S0 + 2 * NV && store_next) {
+        const int idx = st - S0;
+        if (idx & 1) tile_store_one<B_KCONT, MBK, TB>(Bs[PAR ^ 1], tid, idx >> 1, sb_[idx >> 1]);
+        else tile_store_one<A_KCONT, MBK, TB>(As[PAR ^ 1], tid, idx >> 1, sa_[idx >> 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (st == NSTEP - AHEAD - 1) __syncthreads();
+    }
+  };
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+  int it = 0;
+  for (; it + 3 < total; it += 2) {
+    iter_body(c0{}, std::true_type{}, true, true);
+    iter_body(c1{}, std::true_type{}, true, true);
+  }
+  for (; it < total; it += 2) {
+    iter_body(c0{}, std::false_type{}, it + 1 < total, fetched < total);
+    if (it + 1 >= total) break;
+    iter_body(c1{}, std::false_type{}, it + 2 < total, fetched < total);
+  }
+#else
   auto iter_body = [&](auto more_c) {
     constexpr bool MORE = decltype(more_c)::value;
     if constexpr (MORE) {
@@ -452,6 +528,7 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
   };
   for (int it = 0; it + 1 < total; it++) iter_body(std::true_type{});
   if (total > 0) iter_body(std::false_type{});
+#endif
 #else
   for (int it = 0; it < total; it++) {
     const bool more = it + 1 < total;
