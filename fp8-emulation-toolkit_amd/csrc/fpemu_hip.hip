@@ -25,6 +25,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "fpemu_common.hpp"
 
 using namespace fpemu;
@@ -552,6 +554,33 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
   return FPEMU_OK;
 }
 
+// Scratch of the allocation-free entry point (fpemu_quantize_per_tensor_static): word 0 = the amax bit
+// pattern, words 1.. = per-block maxima.  One copy per GPU, held until the process ends (1280 bytes).
+constexpr uint64_t kStaticWords = 320;
+constexpr int kStaticMaxDevices = 64;
+static __device__ __align__(256) uint32_t scratch[kStaticWords];
+static std::atomic<uint32_t *> g_scratch_ptr[kStaticMaxDevices];  // zero-initialised: not looked up yet
+
+// The current device's copy of `scratch` (looked up on the first call on each device).
+int static_scratch(uint32_t **ws) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  if (dev < 0 || dev >= kStaticMaxDevices)
+    return fail(FPEMU_EINVAL, "fpemu_quantize_per_tensor_static: device ordinal beyond the scratch table");
+  uint32_t *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (p == nullptr) {
+    void *sym = nullptr;
+    e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));  // the address on the CURRENT device
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    if (sym == nullptr) return fail(FPEMU_EINVAL, "fpemu_quantize_per_tensor_static: no device address for the scratch");
+    p = static_cast<uint32_t *>(sym);
+    g_scratch_ptr[dev].store(p, std::memory_order_release);  // racing threads look up the same address
+  }
+  *ws = p;
+  return FPEMU_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -777,28 +806,28 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
   return fpemu_cast_scaled(in, out, n, dtype, fmt, rmode, amax_ws, flt_max, clamp, seed, offset, 0, stream);
 }
 
-int fpemu_quantize_per_tensor_ws(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
-                                 float flt_max, int clamp, uint32_t *ws, uint64_t ws_words, uint64_t seed,
-                                 uint64_t offset, void *stream) {
-  if (ws == nullptr || ws_words < 1) return fail(FPEMU_EINVAL, "fpemu_quantize_per_tensor_ws: null workspace");
+// word: receives the amax bit pattern; partials / max_partials: scratch for the per-block maxima (may be 0)
+static int quantize_per_tensor_impl(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
+                                    float flt_max, int clamp, uint32_t *word, uint32_t *partials,
+                                    uint64_t max_partials, uint64_t seed, uint64_t offset, void *stream) {
   if (n == 0) return FPEMU_OK;
   const bool args_ok = in != nullptr && out != nullptr && dtype >= FPEMU_F32 && dtype <= FPEMU_BF16 &&
                        ((uintptr_t)in % elem_size(dtype)) == 0 && ((uintptr_t)out % elem_size(dtype)) == 0;
-  // above the one-workgroup size: two launches -- per-block maxima into ws[1..], then the cast, whose
+  // above the one-workgroup size: two launches -- per-block maxima into the scratch, then the cast, whose
   // blocks each reduce those maxima (L2 hits) -- instead of zero + atomic amax + cast
-  if (args_ok && n > kSmallVectors * vec_elems(dtype) && n * elem_size(dtype) <= kPartialsBytes && ws_words >= 2 &&
+  if (args_ok && n > kSmallVectors * vec_elems(dtype) && n * elem_size(dtype) <= kPartialsBytes && max_partials >= 1 &&
       pick_cast_dt(dtype, fmt, rmode) != nullptr && fmt != BF16 && fmt != FP16 && fmt != FP16_DAZ) {
     const bool vec_ok = ((uintptr_t)in % 16u) == 0;
     const uint64_t nvec = vec_ok ? n / vec_elems(dtype) : 0;
     uint64_t nb = vec_ok ? nvec / 256u : n / 1024u;   // >= one vector (or four elements) per thread
     if (nb > kMaxPartials) nb = kMaxPartials;
-    if (nb > ws_words - 1) nb = ws_words - 1;
+    if (nb > max_partials) nb = max_partials;
     if (nb < 1) nb = 1;
     typedef void (*amax_fn)(const void *, uint64_t, uint64_t, uint32_t *);
     const amax_fn fn = dtype == FPEMU_F32   ? (amax_fn)amax_kernel<FPEMU_F32, true, true>
                        : dtype == FPEMU_F16 ? (amax_fn)amax_kernel<FPEMU_F16, true, true>
                                             : (amax_fn)amax_kernel<FPEMU_BF16, true, true>;
-    hipLaunchKernelGGL(fn, dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, in, nvec, n, ws + 1);
+    hipLaunchKernelGGL(fn, dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, in, nvec, n, partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     CastParams prm;
@@ -810,12 +839,43 @@ int fpemu_quantize_per_tensor_ws(const void *in, void *out, uint64_t n, int dtyp
     prm.rest.seed = seed;
     prm.rest.offset = offset;
     prm.rest.elem_base = 0;
-    prm.rest.partials = ws + 1;
+    prm.rest.partials = partials;
     prm.npart = (uint32_t)nb;
-    prm.rest.amax_pub = ws;
+    prm.rest.amax_pub = word;
     return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
   }
-  return fpemu_quantize_per_tensor(in, out, n, dtype, fmt, rmode, flt_max, clamp, ws, seed, offset, stream);
+  return fpemu_quantize_per_tensor(in, out, n, dtype, fmt, rmode, flt_max, clamp, word, seed, offset, stream);
+}
+
+int fpemu_quantize_per_tensor_ws(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
+                                 float flt_max, int clamp, uint32_t *ws, uint64_t ws_words, uint64_t seed,
+                                 uint64_t offset, void *stream) {
+  if (ws == nullptr || ws_words < 1) return fail(FPEMU_EINVAL, "fpemu_quantize_per_tensor_ws: null workspace");
+  return quantize_per_tensor_impl(in, out, n, dtype, fmt, rmode, flt_max, clamp, ws, ws + 1, ws_words - 1, seed, offset,
+                                  stream);
+}
+
+// fpemu_quantize_per_tensor_static: fpemu_quantize_per_tensor_ws with the library's own scratch instead of a
+// caller-provided workspace, for callers that cannot allocate (HIP graph capture, serving loops).  The scratch
+// is a file-scope __device__ array: every GPU the library runs on holds its own copy at its own address, so
+// the address is looked up once per device (hipGetSymbolAddress with that device current) and only that
+// pointer -- never the array's name, which on the host is a stand-in, not a device address -- is handed to
+// kernels.  Nothing here calls hipMalloc / hipFree or any allocating routine.
+int fpemu_quantize_per_tensor_static(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
+                                     float flt_max, int clamp, uint32_t *amax_out, uint64_t seed,
+                                     uint64_t offset, void *stream) {
+  if (n > FPEMU_STATIC_MAX_ELEMS)
+    return fail(FPEMU_EINVAL, "fpemu_quantize_per_tensor_static: more than FPEMU_STATIC_MAX_ELEMS (2^36) elements");
+  if (n == 0) return FPEMU_OK;
+  uint32_t *ws = nullptr;
+  const int rc = static_scratch(&ws);
+  if (rc != FPEMU_OK) return rc;
+  if (amax_out == nullptr)
+    return fpemu_quantize_per_tensor_ws(in, out, n, dtype, fmt, rmode, flt_max, clamp, ws, kStaticWords, seed, offset,
+                                        stream);
+  // the caller wants the amax word in its own memory: same launches, word 0 redirected
+  return quantize_per_tensor_impl(in, out, n, dtype, fmt, rmode, flt_max, clamp, amax_out, ws + 1, kStaticWords - 1,
+                                  seed, offset, stream);
 }
 
 int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt,

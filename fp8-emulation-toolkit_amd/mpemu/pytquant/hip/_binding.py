@@ -60,6 +60,8 @@ def lib():
         L.fpemu_quantize_per_tensor.argtypes = [vp, vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, vp]
         L.fpemu_quantize_per_tensor_ws.restype = i32
         L.fpemu_quantize_per_tensor_ws.argtypes = [vp, vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, u64, vp]
+        L.fpemu_quantize_per_tensor_static.restype = i32
+        L.fpemu_quantize_per_tensor_static.argtypes = [vp, vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, vp]
         L.fpemu_quantize_rows.restype = i32
         L.fpemu_quantize_rows.argtypes = [vp, vp, u64, u64, i32, i32, i32, f32, i32, u64, u64, vp]
         i64 = ctypes.c_int64
@@ -81,7 +83,7 @@ def lib():
         L.fpemu_quantize_blocks.argtypes = [vp, vp, u64, u64, i32, i32, i32, u64, u64, vp]
         L.fpemu_cast_multi.restype = i32
         L.fpemu_cast_multi.argtypes = [vp, u64, i32, i32, i32, f32, u64, u64, vp]
-        if L.fpemu_abi_version() != 5:
+        if L.fpemu_abi_version() != 6:
             raise ImportError("libfpemu_hip.so: ABI version mismatch")
         _lib = L
     return _lib

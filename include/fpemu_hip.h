@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FPEMU_ABI_VERSION 5
+#define FPEMU_ABI_VERSION 6
 
 /* Storage dtype of in/out buffers. */
 enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
@@ -153,6 +153,24 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
 int fpemu_quantize_per_tensor_ws(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
                                  float flt_max, int clamp, uint32_t *ws, uint64_t ws_words, uint64_t seed,
                                  uint64_t offset, void *stream);
+
+/* fpemu_quantize_per_tensor_ws WITHOUT a workspace argument and without any allocation.  No counterpart in
+ * the reference: it is for callers that cannot allocate device memory or carry a workspace through their
+ * interfaces -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The
+ * scratch (amax word + per-block maxima) is a 1280-byte __device__ array inside the library, one copy per
+ * GPU, held until the process ends; its address is looked up once per device on the first call there
+ * (the stream's device must be the current device, as for every entry point).  Results are bit-identical to
+ * fpemu_quantize_per_tensor_ws with a 257-word workspace.
+ *   amax_out : optional caller-owned device word that receives the amax bit pattern (NULL: not reported);
+ *   n        : at most FPEMU_STATIC_MAX_ELEMS, else FPEMU_EINVAL (nothing is enqueued).
+ * Every call on a GPU shares that GPU's scratch: calls in one stream are ordered and safe; calls that
+ * overlap on one GPU (different streams, or different host threads on different streams) RACE on it --
+ * serialise them or use fpemu_quantize_per_tensor_ws with one workspace per stream.  Calls no hipMalloc,
+ * hipFree or other allocating routine. */
+#define FPEMU_STATIC_MAX_ELEMS (1ull << 36)
+int fpemu_quantize_per_tensor_static(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
+                                     float flt_max, int clamp, uint32_t *amax_out, uint64_t seed,
+                                     uint64_t offset, void *stream);
 
 /* Per-row amax -> scale -> cast of a contiguous [rows, cols] buffer in one launch: row r gets
  * scale_r = fp32(fp32(1/max|row r|) * flt_max) (+ clamp rule when clamp != 0).  Replaces the Python
