@@ -1,0 +1,159 @@
+"""Parity at BASELINE.json's FULL sizes (VERDICT r1 "what's weak" 1).
+
+* configs[1] / [2]: every one of the 12 format x rounding modes on the 1 GiB bench tensor (bench.synth's mix):
+  exact compares against the oracle on windows at the start, around the 2^27 / 2^26 element boundaries, at the
+  ragged end and at 128 random (unaligned) positions -- stochastic modes through `elem_base` windows, which
+  the oracle's Philox stream reproduces -- plus in-place == out-of-place and "a shorter launch over the same
+  buffer gives the same bits" (grid-size independence) over the whole tensor.
+* configs[4], GEMM half: 8192^3 through both kernel variants, a 256 x 256 grid of sampled (i, j) outputs and
+  4 full rows against the sequential-k oracle (reference simple_gemm_impl.cpp:210-231,
+  simple_mm_engine.cpp:13-27).
+* the emulated-FP8 GEMM pipeline: per-tensor E4M3 quantisation of A and B (amax -> device scale -> cast), then
+  the GEMM, at 8192^3, against the oracle pipeline.
+Bit-exact bar throughout."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from _util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N_FULL = 1 << 28
+
+CONFIG2_MODES = ["E5M2_RNE", "E5M2_RTZ", "E5M2_STOCHASTIC", "E4M3_RNE", "E4M3_RTZ", "E4M3_STOCHASTIC",
+                 "E3M4_RNE", "E3M4_RTZ", "E3M4_STOCHASTIC", "BFLOAT16_RNE", "BFLOAT16_RTZ", "BFLOAT16_STOCHASTIC"]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mpemu.pytquant.hip import _binding as b
+
+    b.lib()
+    return b
+
+
+@pytest.fixture(scope="module")
+def bench_tensor():
+    import bench
+
+    x = bench.synth(N_FULL, torch.device(DEV), 1234)
+    torch.cuda.synchronize()
+    yield x
+    del x
+    torch.cuda.empty_cache()
+
+
+def _windows(n):
+    w = [(0, 1 << 20), ((1 << 27) - (1 << 19), (1 << 27) + (1 << 19)), ((1 << 26) - 4099, (1 << 26) + 4099),
+         (n - (1 << 20) - 5, n)]
+    rng = np.random.default_rng(99)
+    for s in rng.integers(0, n - 8192, size=128):
+        w.append((int(s), int(s) + 8192))
+    return w
+
+
+@pytest.mark.parametrize("mode", CONFIG2_MODES)
+def test_config2_every_mode_at_1gib(hip, bench_tensor, mode):
+    x = bench_tensor
+    n = x.numel()
+    fmt, rm = hip.parse_mode(mode)
+    seed, off = 77, 12
+    y = torch.empty_like(x)
+    hip.cast_(x, y, fmt, rm, scale=1.0, seed=seed, offset=off)
+    for a, b in _windows(n):
+        want = orc.cast(x[a:b].cpu().numpy(), mode, seed=seed, offset=off, elem_base=a)
+        assert_bits_equal(y[a:b].cpu().numpy(), want, "%s window [%d, %d)" % (mode, a, b))
+    # in place == out of place, whole tensor
+    xi = x.clone()
+    hip.cast_(xi, xi, fmt, rm, scale=1.0, seed=seed, offset=off)
+    assert torch.equal(xi.view(torch.int32), y.view(torch.int32)), mode + ": in-place differs"
+    # ragged length over the same buffer: a different grid and a per-lane tail, the same bits
+    m = n - 3
+    xi.fill_(0)
+    hip.cast_(x[:m], xi[:m], fmt, rm, scale=1.0, seed=seed, offset=off)
+    assert torch.equal(xi[:m].view(torch.int32), y[:m].view(torch.int32)), mode + ": ragged launch differs"
+    assert float(xi[m:].abs().sum()) == 0.0, mode + ": wrote past the end"
+    del xi, y
+
+
+@pytest.mark.parametrize("mode", ["E4M3_RNE", "E5M2_STOCHASTIC"])
+def test_config2_scaled_at_1gib(hip, bench_tensor, mode):
+    """Per-tensor max scaling at full size (single-word path above 768 MiB): amax word and sampled outputs."""
+    x = bench_tensor.clone()
+    x[~torch.isfinite(x)] = 0.5  # a NaN would make the scale NaN (covered by test_fused_per_tensor_nan_input)
+    n = x.numel()
+    fmt, rm = hip.parse_mode(mode)
+    flt_max = 448.0 if mode.startswith("E4M3") else 57344.0
+    y = torch.empty_like(x)
+    ws = torch.empty(257, dtype=torch.int32, device=DEV)
+    hip.set_rng_state((5, 40))
+    hip.quantize_per_tensor_(x, y, fmt, rm, flt_max, amax_ws=ws)
+    vmax = np.float32(x.abs().max().item())
+    assert int(ws[0].item()) == int(vmax.view(np.uint32))
+    s = orc.scale_from_amax(vmax, flt_max)
+    for a, b in _windows(n)[:40]:
+        want = orc.cast(x[a:b].cpu().numpy(), mode, scale=s, seed=5, offset=40, elem_base=a)
+        assert_bits_equal(y[a:b].cpu().numpy(), want, "%s scaled window [%d, %d)" % (mode, a, b))
+
+
+GEMM_VARIANTS = [("fma", 1, True), ("nofma", 0, False)]
+
+
+def _sample_ij(M, N):
+    rng = np.random.default_rng(8192)
+    i = np.unique(np.concatenate([[0, 127, 128, M - 1], rng.integers(0, M, size=252)]))
+    j = np.unique(np.concatenate([[0, 63, 64, N - 1], rng.integers(0, N, size=252)]))
+    return i, j
+
+
+@pytest.mark.parametrize("bname,variant,fused", GEMM_VARIANTS)
+def test_gemm_8192_sampled(hip, bname, variant, fused):
+    M = N = K = 8192
+    g = torch.Generator(device=DEV).manual_seed(11)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    B = torch.randn(K, N, device=DEV, generator=g)
+    C = torch.zeros(M, N, device=DEV)
+    hip.gemm_(C, A, B, 1.0, False, False, variant)
+    torch.cuda.synchronize()
+    i, j = _sample_ij(M, N)
+    ti, tj = torch.from_numpy(i).to(DEV), torch.from_numpy(j).to(DEV)
+    Bh = B.cpu().numpy()
+    # |i| x |j| sampled outputs (>= 256 x 256 pairs): each a full 8192-step chain
+    want = orc.gemm(A[ti].cpu().numpy(), np.ascontiguousarray(Bh[:, j]), 1.0, fused=fused)
+    got = C[ti][:, tj].cpu().numpy()
+    assert_bits_equal(got, want, "%s 8192^3 sampled grid %dx%d" % (bname, i.size, j.size))
+    # 4 full rows
+    rows = [0, 4095, 4096, M - 1]
+    want = orc.gemm(A[rows].cpu().numpy(), Bh, 1.0, fused=fused)
+    assert_bits_equal(C[rows].cpu().numpy(), want, bname + " 8192^3 full rows")
+
+
+@pytest.mark.parametrize("bname,variant,fused", GEMM_VARIANTS)
+def test_emulated_fp8_gemm_pipeline_8192(hip, bname, variant, fused):
+    """cast -> GEMM as ONE pipeline at BASELINE configs[4]'s GEMM size: A and B are quantised per tensor to
+    E4M3 (amax, device-side scale, cast -- what the hooks do to a Linear's input and weight), then multiplied by
+    the c-model GEMM.  Oracle: the same pipeline on the host (whole-tensor casts, sampled chains)."""
+    M = N = K = 8192
+    g = torch.Generator(device=DEV).manual_seed(12)
+    A = torch.randn(M, K, device=DEV, generator=g) * 3.0
+    B = torch.randn(K, N, device=DEV, generator=g) * 0.02
+    fmt, rm = hip.parse_mode("E4M3_RNE")
+    Aq, Bq = torch.empty_like(A), torch.empty_like(B)
+    hip.quantize_per_tensor_(A, Aq, fmt, rm, 448.0)
+    hip.quantize_per_tensor_(B, Bq, fmt, rm, 448.0)
+    C = torch.zeros(M, N, device=DEV)
+    hip.gemm_(C, Aq, Bq, 1.0, False, False, variant)
+    torch.cuda.synchronize()
+    Ah, Bh = A.cpu().numpy(), B.cpu().numpy()
+    Aqh = orc.cast(Ah, "E4M3_RNE", scale=orc.scale_from_amax(orc.amax(Ah), 448.0))
+    Bqh = orc.cast(Bh, "E4M3_RNE", scale=orc.scale_from_amax(orc.amax(Bh), 448.0))
+    assert_bits_equal(Aq.cpu().numpy(), Aqh, "pipeline: quantised A")
+    assert_bits_equal(Bq.cpu().numpy(), Bqh, "pipeline: quantised B")
+    i, j = _sample_ij(M, N)
+    ti, tj = torch.from_numpy(i).to(DEV), torch.from_numpy(j).to(DEV)
+    want = orc.gemm(Aqh[i], np.ascontiguousarray(Bqh[:, j]), 1.0, fused=fused)
+    assert_bits_equal(C[ti][:, tj].cpu().numpy(), want, bname + " pipeline 8192^3 sampled grid")
+    rows = [1, M - 2]
+    assert_bits_equal(C[rows].cpu().numpy(), orc.gemm(Aqh[rows], Bqh, 1.0, fused=fused), bname + " pipeline rows")
