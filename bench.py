@@ -6,18 +6,27 @@
 One "step" = one pass of the hot path over one batch of synthetic input: the out-of-place
 E4M3_RNE cast (scale 1.0) of a 1 GiB fp32 tensor (BASELINE.json configs[1]) resident in HBM.
 With N > 1 every rank casts its own 1 GiB shard of an N GiB tensor (weak scaling); unscaled
-casts shard with no collective.  Rank 0 prints ONE JSON line.
+casts shard with no collective.  Rank 0 prints ONE JSON line.  `--gpus N` without a
+launcher (WORLD_SIZE unset) starts the N ranks itself through torch.distributed.run; under a launcher
+the world size must equal N.
 
-Extra (untimed for `value`) sections in the same line: per-mode rates for every format x
-rounding mode, the per-tensor-scaled path (amax + all-reduce(max) over RCCL when N > 1 + cast),
-the `roofline` of the dominant kernel from HIP events over the timed region, and `cpu_baseline`: the
-reference's own fpemu_cpp (oracle/_ref, prebuilt from /root/reference; kind "reference") timed on this box's
-host cores on a sample of the same data, with the C restatement (kind "port", OpenMP) beside it -- the port
-alone where the prebuilt extension is absent or does not run on this host.
+Extra (untimed for `value`) sections in the same line, every one of them CHECKED against the oracle on
+a head of its output (`verified`): per-mode rates for every format x rounding mode, the per-tensor-scaled
+path (amax + all-reduce(max) over RCCL when N > 1 + cast), rows / block norm / 16-bit storage, the c-model
+GEMM and convolution, `ceilings` (bare read / write / copy streams timed in this process), the `roofline`
+of the dominant kernel from HIP events over the timed region, and `cpu_baseline`: the reference's own
+fpemu_cpp (oracle/_ref, prebuilt from /root/reference; kind "reference") timed on this box's host cores
+on a sample of the same data, with the C restatement (kind "port", OpenMP) beside it.  With N > 1 rank 0
+also re-casts every rank's shard on its own GPU and compares 64-bit checksums (`extras.sharded_checksums`):
+the N-GPU result is the 1-GPU result of the same global tensor.
 """
 import argparse
+import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +41,10 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SPINUP_STEPS = 64      # untimed launches before the warmup steps (about 20 ms): steady-state clocks
 BYTES_PER_ELEM = 8     # fp32 read + fp32 write, unscaled or given-scale cast
+HEAD = 1 << 22         # elements of every extras leg's output compared with the oracle
+
+CONFIG2_MODES = ("E5M2_RNE", "E5M2_RTZ", "E5M2_STOCHASTIC", "E4M3_RNE", "E4M3_RTZ", "E4M3_STOCHASTIC",
+                 "E3M4_RNE", "E3M4_RTZ", "E3M4_STOCHASTIC", "BFLOAT16_RNE", "BFLOAT16_RTZ", "BFLOAT16_STOCHASTIC")
 
 
 def synth(n, device, seed):
@@ -63,10 +76,23 @@ def time_launches(fn, steps):
     return sum(per) / len(per), min(per)
 
 
+def checksum64(t):
+    """Two 64-bit sums over the bit patterns of a tensor (plain and position-weighted), wrapping."""
+    b = t.reshape(-1).view(torch.int32 if t.element_size() == 4 else torch.int16)
+    s1 = torch.zeros((), dtype=torch.int64, device=t.device)
+    s2 = torch.zeros((), dtype=torch.int64, device=t.device)
+    step = 1 << 26
+    w = (torch.arange(step, device=t.device, dtype=torch.int64) % 8191) + 1
+    for c in range(0, b.numel(), step):
+        v = b[c:c + step].to(torch.int64)
+        s1 += v.sum()
+        s2 += (v * w[: v.numel()]).sum()
+    return [int(s1.item()), int(s2.item())]
+
+
 def reference_baseline(sample, mode, gpu_head):
     """The reference's own fpemu_cpp (oracle/_ref/native, built from /root/reference in the build container)
     timed on this host in a child process; None when the prebuilt extension is absent or does not run here."""
-    import subprocess
     import tempfile
 
     import numpy as np
@@ -98,6 +124,37 @@ def reference_baseline(sample, mode, gpu_head):
             "gpu_matches_reference_on_first_4Mi": bool(np.array_equal(gpu_head, head[: gpu_head.size]))}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher: start the N ranks (one process per GPU) BEFORE this process
+    touches the GPU, and leave with their exit code."""
+    backend = os.environ.get("FPEMU_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()  # does not initialise the GPU
+    if backend == "nccl" and have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible; one rank per GPU over RCCL needs %d.\n"
+                         "(rehearse the multi-process flow on one GPU with FPEMU_BENCH_BACKEND=gloo)\n"
+                         % (args.gpus, have, args.gpus))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def load_ceilings():
+    so = os.path.join(ROOT, "tools", "libfpemu_ceilings.so")
+    if not os.path.isfile(so):
+        return None
+    L = ctypes.CDLL(so)
+    vp, u64 = ctypes.c_void_p, ctypes.c_uint64
+    L.ceil_read.argtypes = [vp, vp, u64, vp]
+    L.ceil_write.argtypes = [vp, u64, vp]
+    L.ceil_copy.argtypes = [vp, vp, u64, ctypes.c_int, vp]
+    return L
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +165,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip per-mode table and cpu baseline")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     if os.environ.get("FPEMU_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
 
@@ -115,6 +174,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: launched with WORLD_SIZE=%d but --gpus %d: they must agree (python -m "
+                         "torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d)\n"
+                         % (world, args.gpus, args.gpus, args.gpus))
+        sys.exit(2)
     # (FPEMU_BENCH_BACKEND=gloo with all ranks on one GPU rehearses the multi-process flow on a 1-GPU box)
     backend = os.environ.get("FPEMU_BENCH_BACKEND", "nccl")
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
@@ -128,12 +192,14 @@ def main():
             dist.init_process_group(backend)
 
     from mpemu.pytquant.hip import _binding as hip
+    from mpemu.sharded import all_reduce_max_words
 
     hip.lib()
     n = args.elems
     x = synth(n, dev, 1234 + rank)
     y = torch.empty_like(x)
     fmt, rm = hip.parse_mode(args.mode)
+    stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
         hip.cast_(x, y, fmt, rm, scale=1.0, seed=1, offset=0, elem_base=rank * n)
@@ -142,15 +208,22 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def all_reduce_max(t):
-        """RCCL reduces the device tensor in stream order.  The gloo rehearsal (ranks sharing one GPU) stages
-        through the host: gloo's own CUDA path hangs on back-to-back calls in that set-up."""
-        if backend == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        else:
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.MAX)
-            t.copy_(h)
+    def reduce_max_f64(v):
+        """MAX of one Python float over the ranks (RCCL on the device; other backends on the host)."""
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_i64(vals):
+        """Every rank's list of 64-bit integers, on every rank: [world][len(vals)]."""
+        if world == 1:
+            return [list(vals)]
+        t = torch.tensor(vals, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return [o.tolist() for o in outs]
 
     # Clock spin-up, untimed, ahead of the W warmup steps: the first ~40 launches after an idle GPU run 2-5 %
     # slower (tools/rampup.py: launches 0-19 include the cold launch, 20-39 6.59 TB/s, from 40 on 6.72-6.74),
@@ -173,62 +246,154 @@ def main():
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    ms = (t1 - t0) * 1e3 / args.steps
-    if world > 1:
-        t = torch.tensor([ms], device=dev, dtype=torch.float64)
-        all_reduce_max(t)
-        ms = float(t.item())
+    ms = reduce_max_f64((t1 - t0) * 1e3 / args.steps)
     value = world * n / (ms * 1e-3)
 
     # roofline of the dominant kernel from the events of the timed region
     per = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     avg_ms, min_ms = sum(per) / len(per), min(per)
     achieved = BYTES_PER_ELEM * n / (avg_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic from the committed PMC passes (profiles/pmc_traffic.json) -- reported only when they were
+    # collected on THIS build of the library (sha256 of libfpemu_hip.so recorded beside them) and workload
+    traffic, traffic_note = None, "no PMC record"
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.isfile(tpath) and n == (1 << 28):  # the PMC passes were run on the default workload
+    if os.path.isfile(tpath) and n == (1 << 28):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            rec = json.load(open(tpath))
+            so_hash = hashlib.sha256(open(hip._SO, "rb").read()).hexdigest()
+            if rec.get("lib_sha256") == so_hash:
+                traffic, traffic_note = rec.get("hbm_bytes_per_launch"), "rocprofv3 --pmc passes on this library build"
+            else:
+                traffic_note = "PMC record is from another build of libfpemu_hip.so: not reported"
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "kernel": "cast_kernel<E4M3,RNE,f32>", "avg_launch_ms": round(avg_ms, 5),
                 "min_launch_ms": round(min_ms, 5), "algorithmic_bytes_per_launch": BYTES_PER_ELEM * n,
                 "timing": "HIP events on the launch stream, one per launch of the timed region"}
 
     extras = {}
     cpu_baseline = None
+    verified = {}
     if not args.no_extras:
-        # scaled path: amax (+ all-reduce(max) of one word over RCCL) + cast, 12 B/elem algorithmic
+        import numpy as np
+
+        import orc
+
+        def same(gpu_t, want, nan_ok=False):
+            g = gpu_t.reshape(-1).view(torch.int32).cpu().numpy().view(np.uint32)
+            w = np.ascontiguousarray(want).reshape(-1).view(np.uint32)
+            if nan_ok:  # a NaN the arithmetic generated: payload is an ISA convention
+                both = ((g & 0x7FFFFFFF) > 0x7F800000) & ((w & 0x7FFFFFFF) > 0x7F800000)
+                return bool(np.all((g == w) | both))
+            return bool(np.array_equal(g, w))
+
+        hx = x[:HEAD].cpu().numpy()
+        base = rank * n
+        step()
+        verified["timed_cast"] = same(y[:HEAD], orc.cast(hx, args.mode, seed=1, offset=0, elem_base=base))
+
+        # ---- ceilings: what the part gives bare streams over the same buffers, in this process -----------------
+        C = load_ceilings() if rank == 0 else None
+        if C is not None:
+            nvec = n // 4
+            legs = {"cast": step,
+                    "read_only": lambda: C.ceil_read(x.data_ptr(), y.data_ptr(), nvec, stream),
+                    "write_only": lambda: C.ceil_write(y.data_ptr(), nvec, stream),
+                    "copy_b128": lambda: C.ceil_copy(x.data_ptr(), y.data_ptr(), nvec, 128, stream),
+                    "copy_b256": lambda: C.ceil_copy(x.data_ptr(), y.data_ptr(), nvec, 256, stream)}
+            ms_c = {k: [] for k in legs}
+            for rnd in range(6):  # interleaved rounds, each leg back to back with itself (steady cache state)
+                for k, f in legs.items():
+                    for _ in range(3):
+                        f()
+                    a, _m = time_launches(f, 10)
+                    if rnd > 0:
+                        ms_c[k].append(a)
+            byts = {"cast": 8 * n, "read_only": 4 * n, "write_only": 4 * n, "copy_b128": 8 * n, "copy_b256": 8 * n}
+            gbs = {k: round(byts[k] / (sorted(v)[len(v) // 2] * 1e-3) / 1e9, 1) for k, v in ms_c.items()}
+            best_copy = max(gbs["copy_b128"], gbs["copy_b256"])
+            extras["ceilings"] = {"GB/s": gbs, "cast_over_best_copy": round(gbs["cast"] / best_copy, 4),
+                                  "how": "tools/ceilings.hip: one 16-byte vector per lane, no loop, nt loads / sc1 nt "
+                                         "stores; median of 5 interleaved rounds x 10 launches, same buffers, same process"}
+            step()  # y holds the cast again
+
+        # ---- scaled path: amax (+ all-reduce(max) of one word over RCCL) + cast, 12 B/elem algorithmic ---------
+        xf = torch.where(torch.isfinite(x), x, torch.full_like(x, 0.5))  # a NaN would make the scale NaN
+        hxf = xf[:HEAD].cpu().numpy()
         ws = torch.zeros(1, dtype=torch.int32, device=dev)
 
         def scaled_step():
             ws.zero_()
-            hip.amax_(x, ws)
+            hip.amax_(xf, ws)
             if world > 1:
-                all_reduce_max(ws)
-            hip.cast_scaled_(x, y, fmt, rm, ws, 448.0, clamp=True, seed=1, offset=0, elem_base=rank * n)
+                all_reduce_max_words(ws)
+            hip.cast_scaled_(xf, y, fmt, rm, ws, 448.0, clamp=True, seed=1, offset=0, elem_base=base)
 
         for _ in range(3):
             scaled_step()
         s_avg, _ = time_launches(scaled_step, 10)
+        gmax = reduce_max_f64(float(xf.abs().max().item()))
+        word_ok = int(ws.item()) == int(np.float32(gmax).view(np.uint32))
+        sc = orc.scale_from_amax(np.float32(gmax), 448.0)
+        verified["scaled_per_tensor"] = word_ok and same(y[:HEAD], orc.cast(hxf, args.mode, scale=sc, seed=1, offset=0,
+                                                                            elem_base=base))
         extras["scaled_per_tensor"] = {"ms_per_step": round(s_avg, 5),
                                        "GB/s_per_gpu": round(12 * n / (s_avg * 1e-3) / 1e9, 1),
-                                       "collective": "all_reduce(max) of 4 B" if world > 1 else "none"}
+                                       "collective": "all_reduce(max) of 4 B" if world > 1 else "none",
+                                       "verified": verified["scaled_per_tensor"]}
 
         if world == 1:
             # the local fused form (no collective): per-block maxima + cast, two launches
             def fused_step():
-                hip.quantize_per_tensor_(x, y, fmt, rm, 448.0)
+                hip.quantize_per_tensor_(xf, y, fmt, rm, 448.0)
 
             for _ in range(3):
                 fused_step()
             f_avg, _ = time_launches(fused_step, 10)
+            verified["fused_per_tensor"] = same(y[:HEAD], orc.cast(hxf, args.mode, scale=sc))
             extras["fused_per_tensor"] = {"ms_per_step": round(f_avg, 5),
-                                          "GB/s_per_gpu": round(12 * n / (f_avg * 1e-3) / 1e9, 1)}
+                                          "GB/s_per_gpu": round(12 * n / (f_avg * 1e-3) / 1e9, 1),
+                                          "verified": verified["fused_per_tensor"]}
 
-        # BASELINE configs[4], one rank's part: an 8 GiB fp32 shard (2^31 elements, past 32-bit indexing) of a
+        # ---- N > 1: the N-GPU result is the 1-GPU result of the same global tensor ----------------
+        if world > 1:
+            sums = {}
+            step()
+            sums["unscaled"] = checksum64(y)
+            f5, r5 = hip.parse_mode("E5M2_STOCHASTIC")
+            hip.cast_(x, y, f5, r5, scale=1.0, seed=7, offset=3, elem_base=base)
+            sums["stochastic"] = checksum64(y)
+            scaled_step()
+            sums["scaled"] = checksum64(y)
+            keys = sorted(sums)
+            allsums = gather_i64([v for k in keys for v in sums[k]])
+            if rank == 0:
+                ok = True
+                shards = [synth(n, dev, 1234 + r) if r else x for r in range(world)]
+                fins = [torch.where(torch.isfinite(s), s, torch.full_like(s, 0.5)) for s in shards]
+                w1 = torch.zeros(1, dtype=torch.int32, device=dev)
+                for s in fins:
+                    hip.amax_(s, w1)  # one GPU, the whole tensor: the word accumulates over the shards
+                for r in range(world):
+                    mine = {}
+                    hip.cast_(shards[r], y, fmt, rm, scale=1.0, seed=1, offset=0, elem_base=r * n)
+                    mine["unscaled"] = checksum64(y)
+                    hip.cast_(shards[r], y, f5, r5, scale=1.0, seed=7, offset=3, elem_base=r * n)
+                    mine["stochastic"] = checksum64(y)
+                    hip.cast_scaled_(fins[r], y, fmt, rm, w1, 448.0, clamp=True, seed=1, offset=0, elem_base=r * n)
+                    mine["scaled"] = checksum64(y)
+                    ok = ok and [v for k in keys for v in mine[k]] == allsums[r]
+                del shards, fins
+                verified["sharded_checksums"] = ok
+                extras["sharded_checksums"] = {"equal_to_single_gpu": ok, "ranks": world, "legs": keys,
+                                               "how": "rank 0 regenerates every rank's shard, casts it on its own GPU "
+                                                      "with that shard's elem_base / the whole tensor's amax word, and "
+                                                      "compares two 64-bit sums per leg with the all-gathered ones"}
+            torch.cuda.empty_cache()
+
+        # ---- BASELINE configs[4], one rank's part: an 8 GiB fp32 shard (2^31 elements, past 32-bit indexing) of a
         # world x 8 GiB tensor -- local amax, all-reduce(max) of the one word over RCCL, cast with the global scale
         try:
             big = 1 << 31
@@ -241,32 +406,43 @@ def main():
                 ws.zero_()
                 hip.amax_(xb, ws)
                 if world > 1:
-                    all_reduce_max(ws)
+                    all_reduce_max_words(ws)
                 hip.cast_scaled_(xb, yb, fmt, rm, ws, 448.0, clamp=True, seed=1, offset=0, elem_base=rank * big)
 
             shard_step()
             b_avg, _ = time_launches(shard_step, 3)
+            bmax = 0.0
+            for c in range(0, big, 1 << 28):
+                bmax = max(bmax, float(xb[c:c + (1 << 28)].abs().max().item()))
+            bmax = reduce_max_f64(bmax)
+            sb = orc.scale_from_amax(np.float32(bmax), 448.0)
+            tail = slice(big - HEAD, big)  # the far end: indices past 2^31 - 2^22
+            verified["shard_8GiB_scaled"] = (int(ws.item()) == int(np.float32(bmax).view(np.uint32))
+                                             and same(yb[tail], orc.cast(xb[tail].cpu().numpy(), args.mode, scale=sb)))
             extras["shard_8GiB_scaled"] = {"ms_per_step": round(b_avg, 4),
                                            "GB/s_per_gpu": round(12 * big / (b_avg * 1e-3) / 1e9, 1),
                                            "tensor_GiB": 8 * world,
-                                           "collective": "all_reduce(max) of 4 B" if world > 1 else "none"}
+                                           "collective": "all_reduce(max) of 4 B" if world > 1 else "none",
+                                           "verified": verified["shard_8GiB_scaled"]}
             del xb, yb
         except torch.cuda.OutOfMemoryError:
             extras["shard_8GiB_scaled"] = "skipped: out of device memory"
         torch.cuda.empty_cache()
+
+        step()
 
         def inplace_step():
             hip.cast_(y, y, fmt, rm, scale=1.0)
 
         inplace_step()
         i_avg, _ = time_launches(inplace_step, 10)
-        extras["inplace"] = {"ms": round(i_avg, 5), "GB/s": round(8 * n / (i_avg * 1e-3) / 1e9, 1)}
+        verified["inplace"] = same(y[:HEAD], orc.cast(orc.cast(hx, args.mode), args.mode))
+        extras["inplace"] = {"ms": round(i_avg, 5), "GB/s": round(8 * n / (i_avg * 1e-3) / 1e9, 1),
+                             "verified": verified["inplace"]}
 
         if rank == 0:
-            modes = {}
-            for m in ("E5M2_RNE", "E5M2_RTZ", "E5M2_STOCHASTIC", "E4M3_RNE", "E4M3_RTZ", "E4M3_STOCHASTIC",
-                      "E3M4_RNE", "E3M4_RTZ", "E3M4_STOCHASTIC", "BFLOAT16_RNE", "BFLOAT16_RTZ",
-                      "BFLOAT16_STOCHASTIC"):
+            modes, modes_ok = {}, {}
+            for m in CONFIG2_MODES:
                 f, r = hip.parse_mode(m)
 
                 def mstep(f=f, r=r):
@@ -275,20 +451,34 @@ def main():
                 mstep()
                 a, _ = time_launches(mstep, 10)
                 modes[m] = round(8 * n / (a * 1e-3) / 1e9, 1)
+                modes_ok[m] = same(y[:HEAD], orc.cast(hx, m, seed=1, offset=3))
             extras["modes_GB/s"] = modes
+            extras["modes_verified"] = modes_ok
+            verified["modes"] = all(modes_ok.values())
 
         if rank == 0 and world == 1:
-            # per-channel rows kernel: 8 B/elem algorithmic (rows of <= 8192 fp32 elements are held
-            # in registers between the row maximum and the cast: one read + one write)
-            xr = x[: 1 << 26]
-            yr = y[: 1 << 26]
+            # per-channel rows kernel: 8 B/elem algorithmic (the row is held on chip between its
+            # maximum and its cast: one read + one write)
+            def rows_oracle(h, cols, clamp=True):
+                out = np.empty_like(h)
+                for r0 in range(0, h.size, cols):
+                    row = h[r0:r0 + cols]
+                    out[r0:r0 + cols] = orc.cast(row, args.mode, scale=orc.scale_from_amax(orc.amax(row), 448.0, clamp=clamp))
+                return out
 
-            def rows_step():
-                hip.quantize_rows_(xr, yr, 16384, fmt, rm, 448.0)
+            for name, rows, cols in (("rows_16384x4096", 16384, 4096), ("rows_4096x11008", 4096, 11008),
+                                     ("rows_1024x65536", 1024, 65536)):
+                xr, yr = xf[: rows * cols], y[: rows * cols]
 
-            rows_step()
-            r_avg, _ = time_launches(rows_step, 10)
-            extras["rows_16384x4096"] = {"ms": round(r_avg, 5), "GB/s": round(8 * xr.numel() / (r_avg * 1e-3) / 1e9, 1)}
+                def rows_step(xr=xr, yr=yr, rows=rows):
+                    hip.quantize_rows_(xr, yr, rows, fmt, rm, 448.0)
+
+                rows_step()
+                r_avg, _ = time_launches(rows_step, 10)
+                hrows = max(1, HEAD // cols)
+                verified[name] = same(yr[: hrows * cols], rows_oracle(xf[: hrows * cols].cpu().numpy(), cols))
+                extras[name] = {"ms": round(r_avg, 5), "GB/s": round(8 * xr.numel() / (r_avg * 1e-3) / 1e9, 1),
+                                "verified": verified[name]}
 
             # 16-bit storage (4 B/elem algorithmic) and block norm (8 B/elem: the block is held in registers
             # between its maximum and its cast, one read + one write)
@@ -300,65 +490,106 @@ def main():
 
             bf16_step()
             b_avg, _ = time_launches(bf16_step, 10)
-            extras["bf16_storage_128Mi"] = {"ms": round(b_avg, 5), "GB/s": round(4 * xb.numel() / (b_avg * 1e-3) / 1e9, 1)}
+            hb = xb[:HEAD].view(torch.int16).cpu().numpy().view(np.uint16)
+            gb = yb[:HEAD].view(torch.int16).cpu().numpy().view(np.uint16)
+            wb = orc.cast16(hb, True, args.mode)
+            isnan = lambda a: (a & 0x7FFF) > 0x7F80
+            verified["bf16_storage_128Mi"] = bool(np.all((gb == wb) | (isnan(gb) & isnan(wb))))
+            extras["bf16_storage_128Mi"] = {"ms": round(b_avg, 5), "GB/s": round(4 * xb.numel() / (b_avg * 1e-3) / 1e9, 1),
+                                            "verified": verified["bf16_storage_128Mi"]}
             del xb, yb
+
+            xr, yr = x[: 1 << 26], y[: 1 << 26]
 
             def bn_step():
                 hip.quantize_blocks_(xr, yr, 64, fmt, rm)
 
             bn_step()
             n_avg, _ = time_launches(bn_step, 10)
-            extras["blocknorm_64_64Mi"] = {"ms": round(n_avg, 5), "GB/s": round(8 * xr.numel() / (n_avg * 1e-3) / 1e9, 1)}
+            verified["blocknorm_64_64Mi"] = same(yr[:HEAD], orc.cast_blocknorm(hx, args.mode, 64), nan_ok=True)
+            extras["blocknorm_64_64Mi"] = {"ms": round(n_avg, 5), "GB/s": round(8 * xr.numel() / (n_avg * 1e-3) / 1e9, 1),
+                                           "verified": verified["blocknorm_64_64Mi"]}
 
             # cmodel emulated GEMM, BASELINE config 5's 8192^3: MFMA fmaf chain and VALU
-            # separate-rounding chain, each against its own roofline (fp32 MFMA 157.3 / VALU mul+add 78.6)
+            # separate-rounding chain, each against its own roofline (fp32 MFMA 157.3 / VALU mul+add 78.6);
+            # a 64 x 64 grid of sampled outputs (full 8192-step chains) against the sequential-k oracle
             M = 8192
             ga = torch.randn(M, M, device=dev)
-            gb = torch.randn(M, M, device=dev)
+            gb_ = torch.randn(M, M, device=dev)
             gc = torch.zeros(M, M, device=dev)
-            for name, variant, peak in (("gemm_8192_mfma_fma_chain", 1, 157.3), ("gemm_8192_valu_separate", 0, 78.6)):
+            si = torch.arange(5, M, 129, device=dev)[:64]
+            sj = torch.arange(3, M, 127, device=dev)[:64]
+            ha, hbm = ga[si].cpu().numpy(), gb_[:, sj].contiguous().cpu().numpy()
+            for name, variant, peak, fused in (("gemm_8192_mfma_fma_chain", 1, 157.3, True),
+                                               ("gemm_8192_valu_separate", 0, 78.6, False)):
                 def gstep(variant=variant):
-                    hip.gemm_(gc, ga, gb, 1.0, False, False, variant)
+                    hip.gemm_(gc, ga, gb_, 1.0, False, False, variant)
 
                 gstep()
                 g_avg, _ = time_launches(gstep, 5)
+                gc.zero_()
+                gstep()
+                verified[name] = same(gc[si][:, sj].contiguous(), orc.gemm(ha, hbm, 1.0, fused=fused))
                 tf = 2.0 * M ** 3 / (g_avg * 1e-3) / 1e12
                 extras[name] = {"ms": round(g_avg, 4), "TFLOP/s": round(tf, 2), "peak": peak,
-                                "frac": round(tf / peak, 4)}
-            del ga, gb, gc
+                                "frac": round(tf / peak, 4), "verified": verified[name]}
+            del ga, gb_, gc
+
+            # cmodel convolution: ResNet-50's 3x3, 64 -> 64 channels, 56 x 56, batch 32
+            try:
+                N_, C_, H_, K_ = 32, 64, 56, 64
+                ci = torch.randn(N_, C_, H_, H_, device=dev)
+                cw = torch.randn(K_, C_, 3, 3, device=dev) * 0.05
+                cb = torch.randn(K_, device=dev)
+                co = torch.empty(N_, K_, H_, H_, device=dev)
+
+                def conv_step():
+                    hip.conv2d_fp_(co, ci, cw, cb, 1, 1)
+
+                conv_step()
+                c_avg, _ = time_launches(conv_step, 10)
+                want = orc.conv2d_fp(ci[:1].cpu().numpy(), cw.cpu().numpy(), cb.cpu().numpy(), 1, 1, fused=True)
+                verified["conv_fp_3x3_c64_56"] = same(co[:1].contiguous(), want)
+                fl = 2.0 * N_ * K_ * H_ * H_ * C_ * 9
+                extras["conv_fp_3x3_c64_56"] = {"ms": round(c_avg, 5), "TFLOP/s_effective": round(fl / (c_avg * 1e-3) / 1e12, 2),
+                                                "verified": verified["conv_fp_3x3_c64_56"]}
+                del ci, cw, cb, co
+            except Exception as e:  # the conv leg must never take the bench line down
+                extras["conv_fp_3x3_c64_56"] = "failed: %r" % (e,)
+                verified["conv_fp_3x3_c64_56"] = False
+        del xf
 
     if rank == 0 and world == 1 and not args.no_extras:
-        import numpy as np
-
-        import orc
-
         sample = min(n, 1 << 28)
-        hx = x[:sample].cpu().numpy()
-        orc.cast(hx[: 1 << 24], args.mode)  # warm pass (threads, page tables)
-        out = np.empty_like(hx)
+        hxs = x[:sample].cpu().numpy()
+        orc.cast(hxs[: 1 << 24], args.mode)  # warm pass (threads, page tables)
+        out = np.empty_like(hxs)
         out.fill(0)
         passes, cpu_s = 0, 0.0
         while passes < 4 or (cpu_s * orc.num_threads() < 15.0 and passes < 40):  # ~15+ core-seconds of work
             c0 = time.perf_counter()
-            orc.cast(hx, args.mode, out=out)
+            orc.cast(hxs, args.mode, out=out)
             cpu_s += time.perf_counter() - c0
             passes += 1
         step()
         torch.cuda.synchronize()
         chk = slice(0, 1 << 22)
         gpu_head = y[chk].cpu().numpy().view(np.uint32)
-        same = bool(np.array_equal(gpu_head, out[chk].view(np.uint32)))
+        same_head = bool(np.array_equal(gpu_head, out[chk].view(np.uint32)))
         port = {"value": round(sample * passes / cpu_s, 1), "unit": "elements/s",
                 "cores": orc.num_threads(), "kind": "port",
                 "sample": "%s over the first %d elements of the same tensor, %d timed passes (%.2f s wall) of "
                           "the OpenMP C oracle (oracle/fpemu_oracle.c), output pre-faulted" % (
                               args.mode, sample, passes, cpu_s),
-                "gpu_matches_oracle_on_first_4Mi": same}
-        cpu_baseline = reference_baseline(hx[: 1 << 26], args.mode, gpu_head) or port
+                "gpu_matches_oracle_on_first_4Mi": same_head}
+        cpu_baseline = reference_baseline(hxs[: 1 << 26], args.mode, gpu_head) or port
         if cpu_baseline is not port:
             cpu_baseline["port"] = port
 
     if rank == 0:
+        if verified:
+            extras["verified"] = verified
+            extras["all_verified"] = all(verified.values())
         line = {
             "metric": "quantized elements/sec, %s fpemu cast of a 1 GiB fp32 tensor per GPU" % args.mode,
             "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps,

@@ -12,7 +12,7 @@
 // without FMA it is a rounded product then a rounded sum.  Both builds are pinned (tests/golden/gemm.npz).
 //
 // gemm_mfma_kernel   the fmaf chain, on v_mfma_f32_32x32x2_f32 (k-ordered, one rounding per step; bit-
-//                    exact against the reference's FMA build).  128x128x16 tiles, 4 waves, each a 64x64
+//                    exact against the reference's FMA build).  128x128x32 tiles, 4 waves, each a 64x64
 //                    quadrant as 2x2 MFMA tiles.  Roofline: fp32 MFMA, 157 TFLOP/s.
 // gemm_mfma16_kernel the same chain on v_mfma_f32_16x16x4_f32 for latency-bound problems (few outputs, long k:
 //                    the conv weight update): a quarter of the per-k latency on four times as many waves.

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <math.h>
 #include <string.h>
 
 #include <atomic>
@@ -47,7 +48,7 @@ constexpr uint64_t kPartialsBytes = 768ull << 20;  // above: zero + atomic amax 
 constexpr uint64_t kMaxPartials = 256;  // one per CU; measured best of 128 / 256 / 512 / 1024 / 2048
 constexpr int kNoRowsKernel = -100;            // fpemu_rows_launch_: no kernel for this fmt/rmode/dtype
 
-int g_max_blocks = 0;
+std::atomic<int> g_max_blocks{0};  // test hook only, see fpemu_test_set_max_blocks_
 thread_local char g_err[256] = "";
 
 int fail(int code, const char *msg) {
@@ -221,7 +222,7 @@ __device__ __forceinline__ void cast_blocks(const void *in_, void *out_, uint64_
       store_stream(&out[v0 + (uint64_t)s * 64u], o);
     }
 
-    sb += nwaves;  // only grids capped by fpemu_set_max_blocks come round again
+    sb += nwaves;  // only grids capped by the test hook come round again
     have = sb < nsb;
     if (have) {
       const uint64_t w0 = sb * (64u * U) + lane;
@@ -312,7 +313,7 @@ __device__ __forceinline__ void cast_blocks_sr(const void *in_, void *out_, uint
     for (int i = 0; i < W; i++) noise.w[i] = draw[(slot * (unsigned)W + (unsigned)i) * 64u + lane];
     store_stream(&out[sb * 256u + slot * 64u + lane], cast_vector<FMT, RM, DT>(v, scale, rcp, noise));
 
-    sb += nblk;  // only grids capped by fpemu_set_max_blocks come round again
+    sb += nblk;  // only grids capped by the test hook come round again
     have = sb < nsb;
     if (have) {
       v = __builtin_nontemporal_load(&in[sb * 256u + slot * 64u + lane]);
@@ -520,7 +521,10 @@ cast_fn pick_cast_dt(int dtype, int fmt, int rm, bool wide = false) {
 }
 
 
-int max_blocks() { return g_max_blocks > 0 ? g_max_blocks : kDefaultMaxBlocks; }
+int max_blocks() {
+  const int mb = g_max_blocks.load(std::memory_order_relaxed);
+  return mb > 0 ? mb : kDefaultMaxBlocks;
+}
 
 int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode,
                 const CastParams &prm, void *stream) {
@@ -592,7 +596,9 @@ void fpemu_set_error_(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", ms
 
 const char *fpemu_last_error(void) { return g_err; }
 
-void fpemu_set_max_blocks(int mb) { g_max_blocks = mb; }
+// TEST-ONLY (not in the public header): cap on workgroups per cast launch, 0 = default.  The suite uses it to
+// drive the kernels' grid-stride loops, which the default one-shot grids never enter; results do not depend on it.
+void fpemu_test_set_max_blocks_(int mb) { g_max_blocks.store(mb, std::memory_order_relaxed); }
 
 int fpemu_parse_mode(const char *mode, int *fmt, int *rmode) {
   static const struct { const char *name; int fmt, rmode; } tab[] = {
@@ -639,7 +645,7 @@ int fpemu_parse_mode(const char *mode, int *fmt, int *rmode) {
 int fpemu_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode, float scale,
                uint64_t seed, uint64_t offset, uint64_t elem_base, void *stream) {
   // the reference aborts the process on scale > FLT_MAX (cpp:772-776); report it instead
-  if (scale > 3.402823466e+38f) return fail(FPEMU_EINVAL, "fpemu_cast: invalid scale factor (inf)");
+  if (!(fabsf(scale) <= 3.402823466e+38f)) return fail(FPEMU_EINVAL, "fpemu_cast: invalid scale factor (inf or nan)");
   CastParams prm;
   prm.scale = scale;
   prm.rcp = (float)(1.0 / (double)scale);  // cpp:714
@@ -659,7 +665,8 @@ int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, i
                      uint64_t seed, uint64_t offset, void *stream) {
   if (count == 0) return FPEMU_OK;
   if (tensors == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast_multi: null tensor table");
-  if (scale > 3.402823466e+38f) return fail(FPEMU_EINVAL, "fpemu_cast_multi: invalid scale factor (inf)");
+  if (!(fabsf(scale) <= 3.402823466e+38f))
+    return fail(FPEMU_EINVAL, "fpemu_cast_multi: invalid scale factor (inf or nan)");
   if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_cast_multi: bad dtype id");
   const cast_multi_fn fn = dtype == FPEMU_F32   ? pick_cast_multi<FPEMU_F32>(fmt, rmode)
                            : dtype == FPEMU_F16 ? pick_cast_multi<FPEMU_F16>(fmt, rmode)
@@ -722,7 +729,8 @@ int fpemu_forward(const void *in, void *out, int dtype, const char *mode, uint64
     block_norm = 0;  // cpp:2020-2025
   // formats whose reference kernel has a block-norm branch; the others ignore the flag (cpp:1913-1957)
   if (block_norm && block_size > 0 && (fmt == E5M2 || fmt == E4M3 || fmt == E3M4 || fmt == E4M3_IEEE || fmt == FP4)) {
-    if (scale > 3.402823466e+38f) return fail(FPEMU_EINVAL, "fpemu_forward: invalid scale factor (inf)");
+    if (!(fabsf(scale) <= 3.402823466e+38f))
+      return fail(FPEMU_EINVAL, "fpemu_forward: invalid scale factor (inf or nan)");
     return fpemu_quantize_blocks(in, out, size, (uint64_t)block_size, dtype, fmt, rmode, seed, offset, stream);
   }
   return fpemu_cast(in, out, size, dtype, fmt, rmode, scale, seed, offset, 0, stream);

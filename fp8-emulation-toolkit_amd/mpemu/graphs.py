@@ -19,6 +19,8 @@ capture, 1.7e-6 apart already without hooks), so compare graph against eager per
 """
 import torch
 
+from .pytquant.hip import _binding as _hip
+
 
 def _flatten(out):
     if isinstance(out, torch.Tensor):
@@ -39,14 +41,18 @@ class GraphedForward(object):
         self.model = model
         self._static_in = [t.clone() if isinstance(t, torch.Tensor) else t for t in example_inputs]
         self._kwargs = example_kwargs
+        dev = next((t.device for t in example_inputs if isinstance(t, torch.Tensor)), torch.device("cuda"))
+        # this graph's own scratch for the per-tensor quantisations, allocated BEFORE capture: the graph bakes
+        # its address in, so it must neither come from another graph's pool nor be shared with eager calls
+        self._ws = torch.empty(_hip._WS_WORDS, dtype=torch.int32, device=dev)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):       # lazy initialisation (workspaces, cuBLAS-style handles) outside capture
+        with torch.cuda.stream(side), torch.no_grad(), _hip.use_workspace(self._ws):
+            for _ in range(warmup):       # lazy initialisation (hipBLASLt handles, ...) outside capture
                 model(*self._static_in, **self._kwargs)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph), _hip.use_workspace(self._ws):
             self._static_out = model(*self._static_in, **self._kwargs)
         self._flat_out = _flatten(self._static_out)
 

@@ -77,8 +77,8 @@ def lib():
             f = getattr(L, nm)
             f.restype = i32
             f.argtypes = [vp, vp, vp] + [i64] * 9 + [i32, vp, u64, vp]
-        L.fpemu_set_max_blocks.restype = None
-        L.fpemu_set_max_blocks.argtypes = [i32]
+        L.fpemu_test_set_max_blocks_.restype = None   # test hook, not part of the public header
+        L.fpemu_test_set_max_blocks_.argtypes = [i32]
         L.fpemu_quantize_blocks.restype = i32
         L.fpemu_quantize_blocks.argtypes = [vp, vp, u64, u64, i32, i32, i32, u64, u64, vp]
         L.fpemu_cast_multi.restype = i32
@@ -179,7 +179,8 @@ _offset = 0
 def manual_seed(seed):
     """Re-key the Philox stream of the stochastic modes and rewind the call counter."""
     global _seed, _offset
-    _seed, _offset = int(seed) & (2 ** 64 - 1), 0
+    with _offset_lock:
+        _seed, _offset = int(seed) & (2 ** 64 - 1), 0
 
 
 def get_rng_state():
@@ -188,16 +189,29 @@ def get_rng_state():
 
 def set_rng_state(state):
     global _seed, _offset
-    _seed, _offset = int(state[0]), int(state[1])
+    with _offset_lock:
+        _seed, _offset = int(state[0]), int(state[1])
+
+
+_offset_lock = threading.Lock()
+
+
+def _take_offsets(count):
+    """Reserve `count` consecutive call offsets (atomic: hooks may run on several host threads)."""
+    global _offset
+    with _offset_lock:
+        o = _offset
+        _offset += count
+    return o
 
 
 def _next_offset(rmode):
-    global _offset
     if rmode != STOCHASTIC:
         return 0
-    o = _offset
-    _offset += 1
-    return o
+    return _take_offsets(1)
+
+
+next_offset = _next_offset
 
 
 def cast_(src, dst, fmt, rmode, scale=1.0, seed=None, offset=None, elem_base=0):
@@ -223,7 +237,6 @@ def cast_multi_(srcs, fmt, rmode, scale=1.0, dsts=None, seed=None, offset=None):
     """Cast a list of contiguous tensors of one dtype on one device (in place unless `dsts` is given) in
     as few launches as possible.  Tensor i gets call offset `offset + i`: the same bits as a loop of
     cast_() calls, and the call counter advances by len(srcs) exactly as that loop would."""
-    global _offset
     srcs = list(srcs)
     dsts = srcs if dsts is None else list(dsts)
     if len(dsts) != len(srcs):
@@ -241,10 +254,7 @@ def cast_multi_(srcs, fmt, rmode, scale=1.0, dsts=None, seed=None, offset=None):
             raise ValueError("fpemu: input/output mismatch")
         tab[i].inp, tab[i].out, tab[i].n = a.data_ptr(), b.data_ptr(), a.numel()
     if offset is None:
-        offset = 0
-        if rmode == STOCHASTIC:
-            offset = _offset
-            _offset += len(srcs)
+        offset = _take_offsets(len(srcs)) if rmode == STOCHASTIC else 0
     with _range("fpemu::cast_multi"), _on_device(first):
         _check(lib().fpemu_cast_multi(ctypes.cast(tab, ctypes.c_void_p), len(srcs), _dtype_id(first), fmt, rmode,
                                       float(scale), _seed if seed is None else seed, offset, _stream(first)))
@@ -275,16 +285,48 @@ def cast_scaled_(src, dst, fmt, rmode, amax_bits, flt_max, clamp=True, seed=None
 
 _WS_WORDS = 1 + 256
 _ws_cache = {}
+_tls = threading.local()
+
+
+class use_workspace(object):
+    """Context: per-tensor quantisation on this host thread uses `ws` (int32, >= 257 words, allocated by the
+    caller) instead of the cached per-stream scratch.  mpemu.graphs.GraphedForward captures under it, so every
+    graph owns the scratch whose address it bakes in."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "ws", None)
+        _tls.ws = self.ws
+        return self.ws
+
+    def __exit__(self, *a):
+        _tls.ws = self.prev
+        return False
 
 
 def _stream_workspace(t, stream):
     """Scratch words for the per-tensor path, one buffer per (device, stream): calls on one stream are
-    ordered, calls on different streams must not share scratch."""
+    ordered, calls on different streams must not share scratch.  Never cached while the stream is being
+    captured into a graph: a buffer allocated there belongs to that graph's private pool, and a later capture
+    (same capture-stream handle) must not bake its address in -- such calls get a buffer of their own."""
+    ws = getattr(_tls, "ws", None)
+    if ws is not None and ws.device == t.device:
+        return ws
     key = (t.device.index, stream)
     ws = _ws_cache.get(key)
     if ws is None:
-        ws = _ws_cache[key] = torch.empty(_WS_WORDS, dtype=torch.int32, device=t.device)
+        ws = torch.empty(_WS_WORDS, dtype=torch.int32, device=t.device)
+        if not torch.cuda.is_current_stream_capturing():
+            _ws_cache[key] = ws
     return ws
+
+
+def stream_workspace(t):
+    """The scratch buffer (int32[257]) of torch's current stream on t's device."""
+    with _on_device(t):
+        return _stream_workspace(t, _stream(t))
 
 
 def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None, clamp=True):
@@ -307,15 +349,13 @@ def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None, clamp=True
 def quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=True):
     """Per-row amax -> scale -> cast of a contiguous buffer viewed as [rows, numel/rows], one launch
     (the per-channel / fine-grained policies of qutils.py:289-337)."""
-    global _offset
     _require_device(src)
     _require_device(dst, "output")
     n = src.numel()
     if rows <= 0 or n % rows:
         raise ValueError("fpemu: %d elements do not split into %d rows" % (n, rows))
-    off = _offset
-    if rmode == STOCHASTIC:
-        _offset += rows  # one call offset per row, as a loop of per-row casts would consume
+    # one call offset per row, as a loop of per-row casts would consume
+    off = _take_offsets(rows) if rmode == STOCHASTIC else _offset
     with _range("fpemu::quantize_rows"), _on_device(src):
         _check(lib().fpemu_quantize_rows(src.data_ptr(), dst.data_ptr(), rows, n // rows, _dtype_id(src),
                                          fmt, rmode, float(flt_max), int(bool(clamp)), _seed, off,
@@ -329,15 +369,12 @@ _BLOCKNORM_FMTS = (0, 1, 2, 7, 8)  # E5M2, E4M3, E3M4, E4M3_IEEE, FP4: reference
 def quantize_blocks_(src, dst, block_size, fmt, rmode):
     """Block-normalised cast (forward(..., block_norm=True, block_size) of the reference): per block of
     block_size consecutive elements the scale comes from the block's max |x|; one launch."""
-    global _offset
     _require_device(src)
     _require_device(dst, "output")
     n = src.numel()
     if block_size <= 0 or n % block_size:
         raise ValueError("fpemu: %d elements do not split into blocks of %d" % (n, block_size))
-    off = _offset
-    if rmode == STOCHASTIC:
-        _offset += n // block_size
+    off = _take_offsets(n // block_size) if rmode == STOCHASTIC else _offset
     with _range("fpemu::quantize_blocks"), _on_device(src):
         _check(lib().fpemu_quantize_blocks(src.data_ptr(), dst.data_ptr(), n, block_size, _dtype_id(src), fmt,
                                            rmode, _seed, off, _stream(src)))

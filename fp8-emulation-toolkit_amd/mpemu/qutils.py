@@ -15,7 +15,9 @@ Results are bit-identical to the reference's CPU path (tests/golden/qtensor.npz)
 
 With `set_amax_process_group(group)` a per-tensor "max" cast treats the tensor as one shard
 of a larger tensor: the local amax word is all-reduced (MAX) over the group before the cast,
-so every rank derives the same scale (DESIGN.md "Multi-GPU").
+so every rank derives the same scale, and the stochastic noise is indexed by the shard's GLOBAL
+position (`elem_base`), so the sharded result is the single-device result bit for bit
+(DESIGN.md "Multi-GPU").
 """
 from collections import OrderedDict
 import copy
@@ -28,12 +30,26 @@ _FLT_MAX = {"e5m2": 57344.0, "e4m3": 448.0, "e4m3_ieee": 240.0, "e3m4": 30.0, "f
 _FLT_MIN = {"e5m2": 1.5258789E-05, "e4m3": 1.9531250E-03, "e3m4": 1.5625000E-02, "fp4": 0.000244140625}
 
 _amax_group = None
+_amax_elem_base = None
 
 
-def set_amax_process_group(group):
-    """group: a torch.distributed process group (or None to go back to single-device scaling)."""
-    global _amax_group
+def set_amax_process_group(group, elem_base=None):
+    """group: a torch.distributed process group (or None to go back to single-device scaling).
+
+    elem_base: where this rank's shard starts in the logical tensor, for the stochastic noise index --
+    None: equal-sized contiguous shards, `rank * tensor.numel()`; an int; or a callable
+    `elem_base(tensor) -> int` for ragged layouts (mpemu.sharded.shard_bounds gives the starts)."""
+    global _amax_group, _amax_elem_base
     _amax_group = group
+    _amax_elem_base = elem_base
+
+
+def _shard_elem_base(tensor):
+    if callable(_amax_elem_base):
+        return int(_amax_elem_base(tensor))
+    if _amax_elem_base is not None:
+        return int(_amax_elem_base)
+    return torch.distributed.get_rank(_amax_group) * tensor.numel()
 
 
 class TensorQuantConfig(object):
@@ -202,10 +218,14 @@ class _ScaledCast(torch.autograd.Function):
         if rows:
             _hip_quantize_rows(src, dst, fmt, rmode, flt_max, rows, clamp)
         elif _amax_group is not None:
-            ws = torch.zeros(1, dtype=torch.int32, device=src.device)
+            from .sharded import all_reduce_max_words
+            ws = _hip.stream_workspace(src)[:1]
+            ws.zero_()
             _hip.amax_(src, ws)
-            torch.distributed.all_reduce(ws, op=torch.distributed.ReduceOp.MAX, group=_amax_group)
-            _hip.cast_scaled_(src, dst, fmt, rmode, ws, flt_max, clamp=clamp)
+            offset = _hip.next_offset(rmode)  # must advance in lock-step on every rank: verified below
+            all_reduce_max_words(ws, _amax_group, check_equal=offset if rmode == _hip.STOCHASTIC else None)
+            _hip.cast_scaled_(src, dst, fmt, rmode, ws, flt_max, clamp=clamp, offset=offset,
+                              elem_base=_shard_elem_base(src))
         else:
             _hip.quantize_per_tensor_(src, dst, fmt, rmode, flt_max, clamp=clamp)
         if inplace:

@@ -69,7 +69,7 @@ enum {
 /* Error codes (negative). */
 enum {
   FPEMU_OK = 0,
-  FPEMU_EINVAL = -1,       /* null pointer, bad dtype/fmt/rmode id, non-finite scale */
+  FPEMU_EINVAL = -1,       /* null pointer, bad dtype/fmt/rmode id, non-finite scale (+-Inf, NaN) */
   FPEMU_EMODE = -2,        /* mode string not recognised (the reference silently no-ops) */
   FPEMU_EUNSUPPORTED = -3, /* recognised but not built (no such case at present) */
   FPEMU_EALIGN = -4        /* pointer not aligned to the element size */
@@ -250,10 +250,6 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
 int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N, int64_t C, int64_t H,
                         int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad, int variant,
                         void *ws, uint64_t ws_bytes, void *stream);
-
-/* Launch-geometry override for benchmarking sweeps: blocks per launch cap (0 = default).
- * Affects performance only, never results. */
-void fpemu_set_max_blocks(int max_blocks);
 
 #ifdef __cplusplus
 }

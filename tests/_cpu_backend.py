@@ -37,3 +37,26 @@ def cast_scaled_(src, dst, fmt, rmode, amax_bits, flt_max, clamp=True, seed=None
     vmax = np.array([int(amax_bits[0])], dtype=np.uint32).view(np.float32)[0]
     s = orc.scale_from_amax(vmax, flt_max, clamp=clamp)
     return cast_(src, dst, fmt, rmode, scale=s, seed=seed, offset=offset, elem_base=elem_base)
+
+
+# ---- what mpemu.qutils' process-group path uses besides the calls above --------------------------------
+STOCHASTIC = 2
+_offset = 0
+_ws = torch.zeros(257, dtype=torch.int32)
+
+
+def next_offset(rmode):
+    global _offset
+    if rmode != STOCHASTIC:
+        return 0
+    _offset += 1
+    return _offset - 1
+
+
+def set_rng_state(state):
+    global _offset
+    _offset = int(state[1])
+
+
+def stream_workspace(t):
+    return _ws

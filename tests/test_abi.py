@@ -64,6 +64,12 @@ def test_argument_errors_without_gpu():
     assert L.fpemu_gemm_f32(18, 16, 16, 4, 4, 4, 4, 4, 4, 1.0, 0, 0, 1, None) == -4   # misaligned C
     assert L.fpemu_cast(18, 18, 16, 0, 1, 1, 1.0, 0, 0, 0, None) == -4           # misaligned fp32
     assert L.fpemu_cast(16, 16, 16, 0, 1, 1, float("inf"), 0, 0, 0, None) == -1  # cpp:772-776
+    assert L.fpemu_cast(16, 16, 16, 0, 1, 1, float("-inf"), 0, 0, 0, None) == -1
+    assert L.fpemu_cast(16, 16, 16, 0, 1, 1, float("nan"), 0, 0, 0, None) == -1  # any non-finite scale
+    assert b"scale" in L.fpemu_last_error()
+    assert L.fpemu_forward(16, 16, 0, b"E4M3_RNE", 16, float("nan"), 0, 1, 0, 0, None) == -1
+    assert L.fpemu_quantize_per_tensor_static(16, 16, (1 << 36) + 1, 0, 1, 1, 448.0, 1, None, 0, 0, None) == -1
+    assert L.fpemu_quantize_per_tensor_static(16, 16, 0, 0, 1, 1, 448.0, 1, None, 0, 0, None) == 0   # empty
     assert L.fpemu_cast(16, 16, 0, 0, 1, 1, 1.0, 0, 0, 0, None) == 0             # empty: no launch
     assert L.fpemu_forward(16, 16, 0, b"NOPE", 16, 1.0, 0, 1, 0, 0, None) == -2
     assert L.fpemu_forward(None, None, 0, b"E4M3_RNE", 16, 1.0, 1, 4, 0, 0, None) == -1  # block_norm: null buffers
@@ -78,6 +84,7 @@ def test_argument_errors_without_gpu():
     assert L.fpemu_cast_multi(tp, 2, 0, 1, 1, 1.0, 0, 0, None) == -1             # null buffer with n > 0
     assert L.fpemu_cast_multi(None, 2, 0, 1, 1, 1.0, 0, 0, None) == -1
     assert L.fpemu_cast_multi(tp, 1, 0, 1, 5, 1.0, 0, 0, None) == -1             # undefined mode pair
+    assert L.fpemu_cast_multi(tp, 1, 0, 1, 1, float("nan"), 0, 0, None) == -1
     tab[1].inp, tab[1].out = 18, 18
     assert L.fpemu_cast_multi(tp, 2, 0, 1, 1, 1.0, 0, 0, None) == -4             # misaligned fp32
     assert L.fpemu_amax(16, 0, 0, 16, None) == 0

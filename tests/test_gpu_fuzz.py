@@ -20,7 +20,7 @@ def hip():
 
     b.lib()
     yield b
-    b.lib().fpemu_set_max_blocks(0)
+    b.lib().fpemu_test_set_max_blocks_(0)
 
 
 def test_random_cases_vs_oracle(hip):
@@ -32,7 +32,7 @@ def test_random_cases_vs_oracle(hip):
         n = int(rng.choice([1, 5, 63, 255, 256, 1023, 1024, 1025, 2047, 4096, 10007, 65536, 250000, (1 << 20) + 3]))
         scale = float(rng.choice([1.0, 1.0, 0.37, 3.0, 116.894, 6.55e4]))
         shift = int(rng.integers(0, 4))                     # leading elements dropped: misaligned views
-        cap = int(rng.choice([0, 0, 1, 7, 64]))             # fpemu_set_max_blocks: looping grids
+        cap = int(rng.choice([0, 0, 1, 7, 64]))             # fpemu_test_set_max_blocks_: looping grids
         sb = 2048 if storage != "f32" else 1024             # stochastic shards start on a superblock of the layout
         elem_base = int(rng.integers(0, 1 << 20)) * sb
         inplace = bool(rng.integers(2))
@@ -40,7 +40,7 @@ def test_random_cases_vs_oracle(hip):
         what = "case %d: %s %s n=%d scale=%r shift=%d cap=%d base=%d inplace=%s" % (
             case, mode, storage, n, scale, shift, cap, elem_base, inplace)
         x = mixed_inputs(n + shift, seed=case)
-        hip.lib().fpemu_set_max_blocks(cap)
+        hip.lib().fpemu_test_set_max_blocks_(cap)
         try:
             if storage == "f32":
                 t = torch.from_numpy(x).to(DEV)[shift:]
@@ -69,7 +69,7 @@ def test_random_cases_vs_oracle(hip):
                 assert np.array_equal(nan, gnan), what
                 assert np.array_equal(got[~nan], want[~nan]), what
         finally:
-            hip.lib().fpemu_set_max_blocks(0)
+            hip.lib().fpemu_test_set_max_blocks_(0)
 
 
 def test_random_rows_and_blocks_vs_oracle(hip):

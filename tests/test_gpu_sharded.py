@@ -1,8 +1,9 @@
 """Sharded cast on the GPU: the HIP path must give the same bits whether a tensor is cast whole
 or as shards (elem_base carries the global index for the stochastic noise; per-tensor scaling
 uses the max-reduced amax word).  The 2-process case shares the one GPU of the test box and
-uses gloo for the 4-byte all-reduce (RCCL refuses two ranks on one device); the data path is
-the real HIP kernels."""
+uses gloo for the 4-byte all-reduce (RCCL refuses two ranks on one device; mpemu.sharded stages the
+words through the host for non-nccl backends); the data path is the real HIP kernels.  With two or more
+GPUs visible the same flow runs over the "nccl" backend (RCCL), one rank per GPU."""
 import os
 import socket
 import sys
@@ -98,3 +99,75 @@ def test_two_processes_one_gpu_global_amax(tmp_path):
     s5 = orc.scale_from_amax(orc.amax(x), 57344.0)
     assert_bits_equal(np.concatenate([p["sr"].numpy() for p in parts]),
                       orc.cast(x, "E5M2_STOCHASTIC", scale=s5, seed=8, offset=2))
+
+
+def _qutils_worker(rank, world, port, n, outdir, backend):
+    for p in (os.path.join(ROOT, "fp8-emulation-toolkit_amd"), os.path.join(ROOT, "oracle"),
+              os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mpemu import qutils
+    from mpemu.pytquant.hip import _binding as hip
+    from mpemu.sharded import ShardedCaster, shard_bounds
+
+    x = _data(n)
+    a, b = shard_bounds(n, world, rank)
+    shard = torch.from_numpy(x[a:b].copy()).to(dev)
+    # (1) through the hooks' entry point: quantize_tensor under set_amax_process_group, stochastic mode
+    qutils.set_amax_process_group(dist.group.WORLD, elem_base=lambda t: a)
+    hip.set_rng_state((1234, 20))
+    cfg = qutils.TensorQuantConfig("e5m2", "stochastic", "per-tensor")
+    q_sr = qutils.quantize_tensor(shard, cfg, None)                     # offset 20
+    q_sr2 = qutils.quantize_tensor(shard, cfg, None)                    # offset 21, back to back
+    q_rne = qutils.quantize_tensor(shard, qutils.TensorQuantConfig("e4m3", "rne", "per-tensor"), None)
+    qutils.set_amax_process_group(None)
+    # (2) ShardedCaster: batched words, many collectives back to back
+    sc = ShardedCaster()
+    for _ in range(20):
+        words = sc.amax_words([shard, shard * 0.5])
+    out = sc.quantize_per_tensor(shard, "E4M3_RNE", 448.0, elem_base=a)
+    torch.cuda.synchronize()
+    torch.save({"sr": q_sr.cpu(), "sr2": q_sr2.cpu(), "rne": q_rne.cpu(), "q": out.cpu(), "words": words.cpu()},
+               os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_qutils_parts(parts, n):
+    x = _data(n)
+    cat = lambda k: np.concatenate([p[k].numpy() for p in parts])
+    s5 = orc.scale_from_amax(orc.amax(x), 57344.0)
+    s4 = orc.scale_from_amax(orc.amax(x), 448.0)
+    assert_bits_equal(cat("sr"), orc.cast(x, "E5M2_STOCHASTIC", scale=s5, seed=1234, offset=20), "quantize_tensor SR")
+    assert_bits_equal(cat("sr2"), orc.cast(x, "E5M2_STOCHASTIC", scale=s5, seed=1234, offset=21), "second SR call")
+    assert_bits_equal(cat("rne"), orc.cast(x, "E4M3_RNE", scale=s4), "quantize_tensor RNE")
+    assert_bits_equal(cat("q"), orc.cast(x, "E4M3_RNE", scale=s4), "ShardedCaster")
+    for p in parts:
+        assert p["words"].view(torch.float32).tolist() == [2500.0, 1250.0]
+
+
+def test_two_processes_one_gpu_quantize_tensor_group_path(tmp_path):
+    """The hooks' entry point under set_amax_process_group, stochastic mode, two ranks sharing the GPU over gloo
+    (host-staged words): the bits of the single-process cast of the whole tensor."""
+    n, world = 300000, 2
+    mp.spawn(_qutils_worker, args=(world, _free_port(), n, str(tmp_path), "gloo"), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True) for r in range(world)]
+    _check_qutils_parts(parts, n)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: fewer than 2 GPUs visible")
+def test_rccl_one_rank_per_gpu(tmp_path):
+    """The first run of the real thing wherever >= 2 GPUs are visible: backend "nccl" (= RCCL), the amax words
+    all-reduced on the device in stream order."""
+    n = 300000
+    world = min(torch.cuda.device_count(), 8)
+    mp.spawn(_qutils_worker, args=(world, _free_port(), n, str(tmp_path), "nccl"), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True) for r in range(world)]
+    _check_qutils_parts(parts, n)

@@ -91,3 +91,91 @@ def test_shard_bounds_cover_and_align():
                 assert a % SHARD_ALIGN == 0 or a == n
                 prev = b
             assert prev == n
+
+
+def _qutils_worker(rank, world, port, n, outdir, skew):
+    """quantize_tensor's process-group path (mpemu/qutils.py _ScaledCast with set_amax_process_group) over gloo,
+    with the oracle-backed stand-in for the HIP ops: global amax, global-index noise, rank-agreed offsets."""
+    for p in (os.path.join(ROOT, "fp8-emulation-toolkit_amd"), os.path.join(ROOT, "oracle"),
+              os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import _cpu_backend
+    from _util import mixed_inputs
+    from mpemu import qutils
+    from mpemu.sharded import shard_bounds
+
+    qutils._hip = _cpu_backend          # the group path only: parse_mode / amax_ / cast_scaled_ / offsets / scratch
+    x = mixed_inputs(n, seed=23)
+    x[~np.isfinite(x) | (np.abs(x) > 1000.0)] = 0.25
+    x[n - 9] = -2750.0                   # the global maximum lives on the last rank
+    a, b = shard_bounds(n, world, rank)
+    shard = torch.from_numpy(x[a:b].copy())
+    qutils.set_amax_process_group(dist.group.WORLD, elem_base=lambda t: a)
+    _cpu_backend.set_rng_state((0, 6 + (skew if rank == 1 else 0)))
+    res = {"err": ""}
+    try:
+        res["sr"] = qutils._ScaledCast.apply(shard, "E5M2_STOCHASTIC", False, 57344.0, 0, True)
+        res["sr2"] = qutils._ScaledCast.apply(shard, "E4M3_STOCHASTIC", False, 448.0, 0, True)   # offset 7
+        res["rne"] = qutils._ScaledCast.apply(shard, "E4M3_RNE", False, 448.0, 0, True)
+    except RuntimeError as e:
+        res["err"] = str(e)
+    torch.save(res, os.path.join(outdir, "rank%d.pt" % rank))
+    qutils.set_amax_process_group(None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_qutils_group_path_is_sharding_invariant_in_stochastic_modes(tmp_path):
+    import orc
+    from _util import assert_bits_equal, mixed_inputs
+
+    n, world = 4096 * 5 + 333, 2
+    mp.spawn(_qutils_worker, args=(world, _free_port(), n, str(tmp_path), 0), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True) for r in range(world)]
+    assert all(p["err"] == "" for p in parts), [p["err"] for p in parts]
+    x = mixed_inputs(n, seed=23)
+    x[~np.isfinite(x) | (np.abs(x) > 1000.0)] = 0.25
+    x[n - 9] = -2750.0
+    cat = lambda k: np.concatenate([p[k].numpy() for p in parts])
+    s5 = orc.scale_from_amax(orc.amax(x), 57344.0)
+    s4 = orc.scale_from_amax(orc.amax(x), 448.0)
+    # the single-process bits: seed 0 (the stand-in's), offsets 6 and 7, noise indexed from element 0 of the WHOLE tensor
+    assert_bits_equal(cat("sr"), orc.cast(x, "E5M2_STOCHASTIC", scale=s5, seed=0, offset=6), "qutils group path, SR")
+    assert_bits_equal(cat("sr2"), orc.cast(x, "E4M3_STOCHASTIC", scale=s4, seed=0, offset=7), "second SR call")
+    assert_bits_equal(cat("rne"), orc.cast(x, "E4M3_RNE", scale=s4), "qutils group path, RNE")
+
+
+def test_qutils_group_path_detects_offset_skew(tmp_path):
+    """Ranks whose stochastic call counters drifted apart would silently draw different noise: refused."""
+    n, world = 5000, 2
+    mp.spawn(_qutils_worker, args=(world, _free_port(), n, str(tmp_path), 3), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True) for r in range(world)]
+    assert all("disagree on the stochastic call offset" in p["err"] for p in parts), [p["err"] for p in parts]
+
+
+def _staging_worker(rank, world, port, outdir):
+    for p in (os.path.join(ROOT, "fp8-emulation-toolkit_amd"),):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mpemu.sharded import all_reduce_max_words, group_backend
+
+    assert group_backend() == "gloo"
+    w = torch.tensor([rank * 10 + 1, 7 - rank, 0], dtype=torch.int32)
+    for _ in range(50):                  # back to back
+        all_reduce_max_words(w)
+    torch.save(w, os.path.join(outdir, "w%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_reduce_max_words_back_to_back(tmp_path):
+    mp.spawn(_staging_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        w = torch.load(os.path.join(str(tmp_path), "w%d.pt" % r), weights_only=True)
+        assert w.tolist() == [11, 7, 0]

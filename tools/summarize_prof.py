@@ -12,7 +12,7 @@ import os
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 os.makedirs("profiles", exist_ok=True)
 
 
@@ -75,6 +75,11 @@ for k, d in pmc.items():
         d["hbm_write_bytes"] = d["WRITE_SIZE_KiB_avg"] * 1024
         out["hbm_bytes_per_launch"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
         out["dominant_kernel"] = k
+import hashlib
+
+_so = os.path.join("fp8-emulation-toolkit_amd", "mpemu", "pytquant", "hip", "libfpemu_hip.so")
+if os.path.isfile(_so):  # bench.py reports this traffic only while the library it loads is this build
+    out["lib_sha256"] = hashlib.sha256(open(_so, "rb").read()).hexdigest()
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 print(open("profiles/%s_kernel_stats.md" % tag).read()[:1500])
