@@ -116,15 +116,31 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out
 // the row (or rows past the end) load a valid dummy address and are masked with selects, so the held
 // vectors stay plain registers; no thread leaves early (the block-wide team has a barrier).
 constexpr int kRegVecs = 8;
+#ifndef FPEMU_ROWS_REG_VECS_F32
+#define FPEMU_ROWS_REG_VECS_F32 8   // tuning: 16 lets 256-thread groups hold rows of up to 16384 fp32 elements
+#endif
+#ifndef FPEMU_ROWS_TIERS
+#define FPEMU_ROWS_TIERS 3          // tuning: bit 0 = the 512-thread tier, bit 1 = the 1024-thread tier
+#endif
+constexpr int reg_vecs(int dtype) { return dtype == FPEMU_F32 ? FPEMU_ROWS_REG_VECS_F32 : kRegVecs; }
 
-template <int FMT, int RM, int DT, int NV>
-__global__ __launch_bounds__(kBlock) void rows_reg_kernel(const void *in_, void *out_, uint64_t rows,
-                                                          uint32_t nv, uint32_t lg, float flt_max, int policy,
-                                                          uint64_t seed, uint64_t offset, uint32_t *amax_out) {
+// BLOCK = kBlock: the general form.  BLOCK = kBigBlock (1024 threads, 16 waves = the whole CU's register file for
+// one row): rows of up to kBigBlock * kBigRegVecs vectors (65536 fp32 / 131072 16-bit elements -- LLM-shaped
+// weight rows of 11008 / 14336 / 16384 columns, block norm with blocks of 16 Ki - 64 Ki), G = BLOCK, one row per
+// workgroup.  The two-pass rows_kernel read such rows twice, the second time mostly from the Infinity Cache:
+// 3.3-3.7 TB/s at 8 B/element where this form streams them once.
+constexpr int kBigBlock = 1024;
+constexpr int kBigRegVecs = 16;
+
+template <int FMT, int RM, int DT, int NV, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *out_, uint64_t rows,
+                                                         uint32_t nv, uint32_t lg, float flt_max, int policy,
+                                                         uint64_t seed, uint64_t offset, uint32_t *amax_out) {
   constexpr unsigned V = Storage<DT>::V;
+  constexpr int kWaves = BLOCK / 64;
   const unsigned G = 1u << lg;
   const unsigned t = threadIdx.x & (G - 1u);
-  const uint64_t row = (((uint64_t)blockIdx.x * kBlock) >> lg) + (threadIdx.x >> lg);
+  const uint64_t row = (((uint64_t)blockIdx.x * BLOCK) >> lg) + (threadIdx.x >> lg);
   const bool live = row < rows;
   const u32x4 *vin = reinterpret_cast<const u32x4 *>(in_) + (live ? row : 0) * nv;
   u32x4 *vout = reinterpret_cast<u32x4 *>(out_) + row * nv;
@@ -155,13 +171,13 @@ __global__ __launch_bounds__(kBlock) void rows_reg_kernel(const void *in_, void 
     }
   }
   uint32_t r = m;
-  if (G == (unsigned)kBlock) {
-    __shared__ uint32_t part[kWavesPerBlock];
+  if (G == (unsigned)BLOCK) {
+    __shared__ uint32_t part[kWaves];
     if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = r;
     __syncthreads();
     r = part[0];
 #pragma unroll
-    for (int w = 1; w < kWavesPerBlock; w++) r = r > part[w] ? r : part[w];
+    for (int w = 1; w < kWaves; w++) r = r > part[w] ? r : part[w];
   }
   if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
   else if constexpr (DT == FPEMU_BF16) r = r << 16;
@@ -181,9 +197,9 @@ __global__ __launch_bounds__(kBlock) void rows_reg_kernel(const void *in_, void 
 typedef void (*rows_reg_fn)(const void *, void *, uint64_t, uint32_t, uint32_t, float, int, uint64_t, uint64_t,
                             uint32_t *);
 
-template <int DT, int NV> rows_reg_fn pick_rows_reg(int fmt, int rm) {
+template <int DT, int NV, int BLOCK = kBlock> rows_reg_fn pick_rows_reg(int fmt, int rm) {
 #define FPEMU_CASE(F, R) \
-  if (fmt == F && rm == R) return rows_reg_kernel<F, R, DT, NV>;
+  if (fmt == F && rm == R) return rows_reg_kernel<F, R, DT, NV, BLOCK>;
   FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
   FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
   FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
@@ -200,7 +216,23 @@ template <int DT> rows_reg_fn pick_rows_reg_nv(uint32_t per_lane, int fmt, int r
   return per_lane <= 1 ? pick_rows_reg<DT, 1>(fmt, rm)
        : per_lane <= 2 ? pick_rows_reg<DT, 2>(fmt, rm)
        : per_lane <= 4 ? pick_rows_reg<DT, 4>(fmt, rm)
-                       : pick_rows_reg<DT, kRegVecs>(fmt, rm);
+       : (per_lane <= 8 || DT != FPEMU_F32 || FPEMU_ROWS_REG_VECS_F32 <= 8) ? pick_rows_reg<DT, kRegVecs>(fmt, rm)
+                       : pick_rows_reg<DT, (DT == FPEMU_F32 ? FPEMU_ROWS_REG_VECS_F32 : kRegVecs)>(fmt, rm);
+}
+
+// 16-bit storage stops at 8 vectors per lane (65536 elements): with 16 the kernel spills (128 VGPRs at 16 waves)
+constexpr int big_reg_vecs(int dtype) { return dtype == FPEMU_F32 ? kBigRegVecs : 8; }
+
+template <int DT, int BLOCK> rows_reg_fn pick_rows_big_nv(uint32_t per_lane, int fmt, int rm) {
+  if (per_lane <= 4) return pick_rows_reg<DT, 4, BLOCK>(fmt, rm);
+  if (per_lane <= 8) return pick_rows_reg<DT, 8, BLOCK>(fmt, rm);
+  if constexpr (DT == FPEMU_F32) return pick_rows_reg<DT, kBigRegVecs, BLOCK>(fmt, rm);
+  else return nullptr;
+}
+template <int BLOCK> rows_reg_fn pick_rows_big(int dtype, uint32_t per_lane, int fmt, int rm) {
+  return dtype == FPEMU_F32 ? pick_rows_big_nv<FPEMU_F32, BLOCK>(per_lane, fmt, rm)
+       : dtype == FPEMU_F16 ? pick_rows_big_nv<FPEMU_F16, BLOCK>(per_lane, fmt, rm)
+       : dtype == FPEMU_BF16 ? pick_rows_big_nv<FPEMU_BF16, BLOCK>(per_lane, fmt, rm) : nullptr;
 }
 
 // Blocks shorter than one 16-byte vector (the emulators' block_size = 1 on embedding tables,
@@ -347,7 +379,7 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
     return FPEMU_OK;
   }
   // register-resident path: aligned rows of at most kBlock * kRegVecs vectors
-  if ((((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % ve) == 0 && cols / ve <= (uint64_t)kBlock * kRegVecs) {
+  if ((((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % ve) == 0 && cols / ve <= (uint64_t)kBlock * (unsigned)reg_vecs(dtype)) {
     const uint32_t nv = (uint32_t)(cols / ve);
     // lane group: the smallest power of two covering the row's vectors, up to a wave; longer rows keep the
     // wave (<= 4 vectors per lane) or take the whole block; a lone row is spread over the block
@@ -374,6 +406,34 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
       return (int)e;
     }
     return FPEMU_OK;
+  }
+  // longer aligned rows, up to kBigBlock * kBigRegVecs vectors: the 512- / 1024-thread register-resident forms
+  if ((((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % ve) == 0 &&
+      cols / ve <= (uint64_t)kBigBlock * (unsigned)big_reg_vecs(dtype)) {
+    const uint32_t nv = (uint32_t)(cols / ve);
+    // Measured on MI355X (tools/rows_quick.py, 64 Mi elements, TB/s at 8 | 4 B/element; 1024- vs 512-thread groups):
+    // fp32 rows of 16384: 5.85 vs 5.75, of 32768: 5.43 vs 5.85; bf16 rows of 32768: 4.7 vs 5.25.  So fp32 takes
+    // 512 threads only where 1024 would hold more than four vectors per lane; 16-bit storage wherever they fit.
+    const bool mid = (FPEMU_ROWS_TIERS & 1) && nv <= 512u * (unsigned)big_reg_vecs(dtype) &&
+                     (dtype != FPEMU_F32 || nv > 4u * (unsigned)kBigBlock || !(FPEMU_ROWS_TIERS & 2));
+    if (mid || (FPEMU_ROWS_TIERS & 2)) {
+      const uint32_t block = mid ? 512u : (uint32_t)kBigBlock;
+      const uint32_t per_lane = (nv + block - 1u) / block;
+      rows_reg_fn rf = mid ? pick_rows_big<512>(dtype, per_lane, fmt, rmode) : pick_rows_big<kBigBlock>(dtype, per_lane, fmt, rmode);
+      if (rf == nullptr) return -100;  // kNoRowsKernel of fpemu_hip.hip
+      if (rows > 0x7FFFFFFFull) {
+        fpemu_set_error_("fpemu rows: more than 2^31-1 workgroups");
+        return FPEMU_EINVAL;
+      }
+      hipLaunchKernelGGL(rf, dim3((unsigned)rows), dim3(block), 0, (hipStream_t)stream, in, out, rows, nv,
+                         mid ? 9u : 10u, flt_max, policy, seed, offset, amax_out);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) {
+        fpemu_set_error_(hipGetErrorString(e));
+        return (int)e;
+      }
+      return FPEMU_OK;
+    }
   }
   const int team = (force_block || rows == 1 || cols > kWaveRowCols) ? kBlock : cols > kLaneRowCols ? 64 : 1;
   // 16-byte accesses only when every lane of the team gets at least one vector; shorter rows go one

@@ -19,6 +19,11 @@ Fixtures (all loadable with numpy.load(allow_pickle=False) / json):
   models.npz      reference mpt_emu.quantize_model / scale_shift on tiny seeded models
   gemm.npz        reference cmodel simple_gemm_dev.gemm, FMA build and -mno-fma build
   conv.npz        reference cmodel simple_conv2d_dev conv2d_fp / _bp / _wu, FMA build and -mno-fma build
+  callers.json    repr of every model_qconfig_dict entry the reference's four emulators build for a module holding
+                  every whitelisted type (training / inference / calibration, with and without exempt / fused lists)
+  callers.npz     training-mode hooks (HybridEmulator / E5M2Emulator / E4M3Emulator(train=True), optimizer=None) on a
+                  tiny MLP: hooked weights and layer inputs after a forward pass; a 2-layer tiny BERT built with the
+                  module_wrappers through mpt_emu.quantize_model(dtype="e4m3" / "hybrid"): weights, hook inputs, output
   ext2.npz        E4M3_IEEE_RNE (AVX-512 routine = canonical), FP4_NEAREST, block_norm=True outputs,
                   E4M3_IEEE_STOCHASTIC round-up counts
 """
@@ -420,8 +425,108 @@ def gen_models():
     np.savez_compressed(os.path.join(HERE, "models.npz"), **out)
 
 
+def gen_callers():
+    """The callers of the cast, pinned against the reference's own Python (CPU): which module gets which
+    config (reprs), and the tensors the training-mode and wrapper-module hooks produce."""
+    import copy
+
+    build_ref.import_reference_package("scalar")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _zoo
+    from mpemu import mpt_emu
+    from mpemu.e3m4_emu import E3M4Emulator
+    from mpemu.e4m3_emu import E4M3Emulator
+    from mpemu.e5m2_emu import E5M2Emulator
+    from mpemu.hybrid_emu import HybridEmulator
+
+    classes = {"e5m2": E5M2Emulator, "e4m3": E4M3Emulator, "e3m4": E3M4Emulator, "hybrid": HybridEmulator}
+    cfgs = {}
+    torch.manual_seed(99)
+    zoo0 = _zoo.Zoo()
+    for cname, cls in classes.items():
+        for phase in ("training", "inference", "calibrate"):
+            for lists in ("none", "lists"):
+                zoo = copy.deepcopy(zoo0)
+                zoo.train(phase == "training")
+                if cname == "e4m3":
+                    emu = cls(zoo, None, device="cpu", train=(phase == "training"))
+                else:
+                    emu = cls(zoo, None, device="cpu")
+                if phase == "inference":
+                    emu.is_training = False
+                    emu.set_default_inference_qconfig()
+                elif phase == "calibrate":
+                    emu.is_training = False
+                    emu.set_calibration_qconfig()
+                exempt, fused = (None, None) if lists == "none" else (["lin2", "block.0"], ["lin1", "mm", "lin2"])
+                key = "%s/%s/%s" % (cname, phase, lists)
+                try:
+                    emu.prepare_model(zoo, exempt, fused)
+                    cfgs[key] = {"is_training": bool(emu.is_training),
+                                 "modules": {k: repr(v) for k, v in emu.model_qconfig_dict.items()},
+                                 "unpatched": list(emu.list_unpatched)}
+                except Exception as e:  # the reference's own failure modes are part of the record
+                    cfgs[key] = {"error": type(e).__name__}
+    json.dump(cfgs, open(os.path.join(HERE, "callers.json"), "w"), indent=1, sort_keys=True)
+
+    out = {}
+    x = torch.randn(20, 24, generator=torch.Generator().manual_seed(8)) * 1.5
+    out["mlp_x"] = x.numpy().view(np.uint32)
+    mlp0 = _zoo.tiny_mlp()
+    for k, v in mlp0.state_dict().items():
+        out["mlp_init/" + k] = v.numpy().view(np.uint32)
+    for cname in ("hybrid", "e5m2", "e4m3"):
+        m = copy.deepcopy(mlp0).train()
+        emu = classes[cname](m, None, device="cpu", train=True) if cname == "e4m3" else classes[cname](m, None, device="cpu")
+        emu.prepare_model(m, None, None)
+        seen = {}
+        hs = [m[i].register_forward_hook(lambda mod, inp, o, i=i: seen.__setitem__(i, (inp[0].detach().clone(), o.detach().clone())))
+              for i in (0, 2)]
+        y = m(x.clone())
+        tag = "mlp_train/%s/" % cname
+        out[tag + "w0"] = m[0].weight.detach().numpy().view(np.uint32)
+        out[tag + "w2"] = m[2].weight.detach().numpy().view(np.uint32)
+        out[tag + "in0"] = seen[0][0].numpy().view(np.uint32)
+        out[tag + "in2"] = seen[2][0].numpy().view(np.uint32)
+        out[tag + "out0"] = seen[0][1].numpy().view(np.uint32)
+        out[tag + "y"] = y.detach().numpy().view(np.uint32)
+        for h in hs:
+            h.remove()
+
+    bert0, ids = _zoo.tiny_bert()
+    out["bert_ids"] = ids.numpy().astype(np.int64)
+    for k, v in bert0.state_dict().items():
+        out["bert_init/" + k] = v.numpy().view(np.uint32)
+    bcfg = {}
+    for dtype in ("e4m3", "hybrid"):
+        m = copy.deepcopy(bert0).eval()
+        m, mpt = mpt_emu.quantize_model(m, dtype=dtype, device="cpu",
+                                        list_layers_output_fused=None, list_exempt_layers=None)
+        bcfg[dtype] = {k: repr(v) for k, v in mpt.emulator.model_qconfig_dict.items()}
+        seen = {}
+        names = ["layers.0.q", "layers.0.scores", "layers.0.context", "layers.0.ff1", "layers.1.res2", "pool"]
+        mods = dict(m.named_modules())
+        hs = [mods[n].register_forward_hook(lambda mod, inp, o, n=n: seen.__setitem__(n, [t.detach().clone() for t in inp if torch.is_tensor(t)]))
+              for n in names]
+        with torch.no_grad():
+            y = m(ids)
+        tag = "bert/%s/" % dtype
+        for k, v in m.state_dict().items():
+            out[tag + "w/" + k] = v.numpy().view(np.uint32)
+        for n in names:
+            for j, t in enumerate(seen[n]):
+                out[tag + "in/%s/%d" % (n, j)] = t.contiguous().numpy().view(np.uint32)
+        out[tag + "y"] = y.numpy().view(np.uint32)
+        for h in hs:
+            h.remove()
+    cfgs_b = json.load(open(os.path.join(HERE, "callers.json")))
+    cfgs_b["tiny_bert"] = bcfg
+    json.dump(cfgs_b, open(os.path.join(HERE, "callers.json"), "w"), indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "callers.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor", "models", "gemm", "ext2", "conv"]
+    which = sys.argv[1:] or ["luts", "rawbits", "scaled", "testpy64", "sr_hist", "qtensor", "models", "gemm", "ext2", "conv", "callers"]
     for w in which:
         globals()["gen_" + w]()
         print("golden:", w, "done")

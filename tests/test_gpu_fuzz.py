@@ -74,13 +74,13 @@ def test_random_cases_vs_oracle(hip):
 
 def test_random_rows_and_blocks_vs_oracle(hip):
     """Per-row (per-channel, clamped or not) and block-norm quantisation over random shapes -- every team shape of
-    the rows kernels (sub-vector, lane groups of 1..256 lanes with 1..8 held vectors, two-pass wave / block
+    the rows kernels (sub-vector, lane groups of 1..256 lanes with 1..8 held vectors, 1024-thread groups with 4..16, two-pass wave / block
     teams, unaligned rows) -- against the oracle's loop of per-row casts."""
     from _util import FLT_MAX
 
     rng = np.random.default_rng(7)
     modes = ["E4M3_RNE", "E5M2_RNE", "E3M4_RNE", "E4M3_STOCHASTIC", "E5M2_STOCHASTIC", "E4M3_RTZ", "E5M2_RNAZ"]
-    col_choices = [1, 2, 3, 4, 7, 8, 16, 20, 64, 100, 256, 260, 768, 1000, 1024, 1028, 4096, 8192, 8196, 12288, 20000]
+    col_choices = [1, 2, 3, 4, 7, 8, 16, 20, 64, 100, 256, 260, 768, 1000, 1024, 1028, 4096, 8192, 8196, 11008, 12288, 16384, 20000, 32768, 50000, 65536, 65540]
     for case in range(120):
         mode = modes[int(rng.integers(len(modes)))]
         fmt, rm = hip.parse_mode(mode)

@@ -307,7 +307,11 @@ def test_device_scale_random_amax_sweep(hip):
 # rows kernel: per-channel / fine-grained scaling in one launch
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("rows,cols", [(1, 1), (3, 7), (64, 147), (17, 1024), (768, 768), (5, 70001),
-                                       (3072, 768), (2, 262144), (1000, 36), (37, 2304), (9, 8192)])
+                                       (3072, 768), (2, 262144), (1000, 36), (37, 2304), (9, 8192),
+                                       # the 1024-thread register-resident form: 4 / 8 / 16 vectors per lane,
+                                       # whole and ragged last slots, LLM-shaped rows, the edge to the two-pass form
+                                       (300, 11008), (40, 14336), (33, 16384), (7, 8196), (6, 40000), (5, 65536),
+                                       (3, 65540), (3, 32772)])
 @pytest.mark.parametrize("mode,clamp", [("E4M3_RNE", True), ("E5M2_RNE", True), ("E3M4_RNE", False),
                                         ("E5M2_STOCHASTIC", True), ("E4M3_RTZ", False)])
 def test_rows_kernel_vs_oracle_loop(hip, rows, cols, mode, clamp):
@@ -335,7 +339,7 @@ def test_rows_kernel_vs_oracle_loop(hip, rows, cols, mode, clamp):
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_rows_kernel_16bit_storage(hip, dt):
     fmt, rm = hip.parse_mode("E4M3_RNE")
-    for rows, cols in ((9, 33), (40, 256)):
+    for rows, cols in ((9, 33), (40, 256), (20, 16392), (11, 28672), (5, 65536), (3, 65544), (2, 131072)):
         t = (torch.randn(rows, cols, device=DEV) * 3).to(dt)
         o = torch.empty_like(t)
         hip.quantize_rows_(t, o, rows, fmt, rm, 448.0)
