@@ -180,6 +180,38 @@ __global__ __launch_bounds__(NT) void cols_bp(const float *__restrict__ go, floa
   }
 }
 
+// Implicit-GEMM path (stride 1, 64-channel blocks, fmaf-chain variant): instead of gathering R*S shifted copies
+// of every plane, zero-pad the planes ONCE; the chain GEMM then reads row (c, kj, ki) of its operand as plane c
+// shifted by kj*Wp + ki (fpemu_gemm.hip, ConvMap).  xp[n][c][y][x] = x[n][c][y - ph][x - pw], 0 outside.
+// Four consecutive elements per thread, one 16-byte store.
+__global__ __launch_bounds__(NT) void pad_planes(const float *__restrict__ x, float *__restrict__ xp, int64_t planes,
+                                                 int H, int W, int Hp, int Wp, int ph, int pw) {
+  const int64_t plane = (int64_t)Hp * Wp, total = planes * plane;
+  for (int64_t i = gtid() * 4; i < total; i += gstride() * 4) {
+    f32x4 o;
+    int64_t pl = i / plane;
+    int rem = (int)(i - pl * plane);
+    int y = rem / Wp, xx = rem - y * Wp;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int sy = y - ph, sx = xx - pw;
+      float v = 0.f;
+      if (i + e < total && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W)
+        v = x[(pl * H + sy) * (int64_t)W + sx];
+      o[e] = v;
+      if (++xx == Wp) {
+        xx = 0;
+        if (++y == Hp) { y = 0; pl++; }
+      }
+    }
+    if (i + 3 < total) {
+      *reinterpret_cast<f32x4 *>(xp + i) = o;
+    } else {
+      for (int e = 0; e < 4 && i + e < total; e++) xp[i + e] = o[e];
+    }
+  }
+}
+
 // out[n][k][p] = bias[k] (+0 when channel padding exists in the reference: turns a -0 bias into +0), or 0
 __global__ __launch_bounds__(NT) void fill_rows(float *__restrict__ out, const float *__restrict__ bias,
                                                 int64_t rows_per_img, int64_t P, int64_t total, int add_zero) {
@@ -256,11 +288,52 @@ int64_t chunk_images(const Geo &g, int64_t per_img, int64_t avail_floats) {
   return c;
 }
 
+// Implicit path: floats of padded planes for `imgs` images plus the read-ahead slack of the last tile
+int64_t implicit_floats(int64_t imgs, int64_t chans, int64_t Hp, int64_t Wp, int64_t R, int64_t S) {
+  return imgs * chans * Hp * Wp + 128 + R * Wp + S + 4;
+}
+
 #define CHECK_LAUNCH(who)                                               \
   do {                                                                  \
     hipError_t e_ = hipGetLastError();                                  \
     if (e_ != hipSuccess) return fail(who, (int)e_, hipGetErrorString(e_)); \
   } while (0)
+
+}  // namespace
+
+extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float *xp, const float *bias, int64_t batch,
+                                       int64_t M, int64_t cblocks, int64_t R, int64_t S, int64_t plane, int64_t Wp,
+                                       int64_t OH, int64_t OW, int reverse, void *stream);
+
+namespace {
+
+// out[n][m][oy][ox] (OH x OW) = chain(bias[m]; (cb, kj, ki, c2) ascending: Wm[m][...] * src[n][cb*64+c2][oy+kj-ph][ox+ki'-pw]),
+// ki' = ki, or S-1-ki when `reverse` (backward-data walks ki ascending = source column descending),
+// for a stride-1 correlation of `chans` (multiple of 64) source channels of Hs x Ws with an R x S filter.
+// Returns FPEMU_OK, an error, or 1 when the workspace cannot hold even one image (caller falls back).
+int implicit_conv(const char *who, float *out, const float *src, const float *Wm, const float *bias, int64_t N,
+                  int64_t chans, int64_t Hs, int64_t Ws, int64_t M, int64_t R, int64_t S, int64_t ph, int64_t pw,
+                  int64_t OH, int64_t OW, int reverse, float *xp, int64_t xp_floats, hipStream_t s) {
+  const int64_t Hp = Hs + 2 * ph, Wp = Ws + 2 * pw;
+  int64_t chunk = N;
+  while (chunk > 1 && implicit_floats(chunk, chans, Hp, Wp, R, S) > xp_floats) chunk = (chunk + 1) / 2;
+  if (implicit_floats(chunk, chans, Hp, Wp, R, S) > xp_floats) return 1;
+  if (chunk > 65535) chunk = 65535;
+  for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+    const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
+    hipLaunchKernelGGL(pad_planes, dim3(blocks_for((nb * chans * Hp * Wp + 3) / 4)), dim3(NT), 0, s,
+                       src + n0 * chans * Hs * Ws, xp, nb * chans, (int)Hs, (int)Ws, (int)Hp, (int)Wp, (int)ph, (int)pw);
+    CHECK_LAUNCH(who);
+    const int rc = fpemu_gemm_conv_launch_(out + n0 * M * OH * OW, Wm, xp, bias, nb, M, chans / 64, R, S, Hp * Wp, Wp,
+                                           OH, OW, reverse, (void *)s);
+    if (rc != 0) return fail(who, rc, hipGetErrorString((hipError_t)rc));
+  }
+  return FPEMU_OK;
+}
+
+#ifndef FPEMU_CONV_IMPLICIT
+#define FPEMU_CONV_IMPLICIT 1
+#endif
 
 }  // namespace
 
@@ -276,7 +349,8 @@ uint64_t fpemu_conv2d_workspace_bytes(int kind, int64_t N, int64_t C, int64_t H,
   int64_t imgs = per > 0 ? kColsCapFloats / per : N;
   if (imgs < 1) imgs = 1;
   if (imgs > N) imgs = N;
-  return (uint64_t)(wf + imgs * per) * 4u;
+  // (+ the read-ahead slack of the implicit path's last tile, so a 1 x 1 convolution's planes fit whole)
+  return (uint64_t)(wf + imgs * per + 128 + R * (W + 2 * pad + R) + S + 4) * 4u;
 }
 
 int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float *bias, int64_t N, int64_t C,
@@ -292,11 +366,18 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   int64_t wf, per;
   ws_layout(FPEMU_CONV_FP, g, wf, per);
   const int64_t chunk = chunk_images(g, per, (int64_t)(ws_bytes / 4) - wf);
-  if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
+  if ((int64_t)(ws_bytes / 4) < wf) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   hipStream_t s = (hipStream_t)stream;
   float *Wm = (float *)ws, *cols = Wm + wf;
   const int64_t P = g.OH * g.OW, crs = C * R * S;
   hipLaunchKernelGGL(pack_w_fp, dim3(blocks_for(K * crs)), dim3(NT), 0, s, w, Wm, g);
+  CHECK_LAUNCH(who);
+  if (FPEMU_CONV_IMPLICIT && variant == 1 && stride == 1 && C % 64 == 0 && K % 64 == 0) {
+    rc = implicit_conv(who, out, in, Wm, bias, N, C, H, W, K, R, S, pad, pad, g.OH, g.OW, 0, cols,
+                       (int64_t)(ws_bytes / 4) - wf, s);
+    if (rc != 1) return rc;  // 1: workspace too small for the padded planes -> the gathered form below
+  }
+  if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   hipLaunchKernelGGL(fill_rows, dim3(blocks_for(N * K * P)), dim3(NT), 0, s, out, bias, K, P, N * K * P,
                      (int)(C % 64 != 0));
   CHECK_LAUNCH(who);
@@ -325,11 +406,21 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
   int64_t wf, per;
   ws_layout(FPEMU_CONV_BP, g, wf, per);
   const int64_t chunk = chunk_images(g, per, (int64_t)(ws_bytes / 4) - wf);
-  if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
+  if ((int64_t)(ws_bytes / 4) < wf) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   hipStream_t s = (hipStream_t)stream;
   float *Wm = (float *)ws, *cols = Wm + wf;
   const int64_t HW = H * W, krs = K * R * S, P = g.OH * g.OW;
   hipLaunchKernelGGL(pack_w_bp, dim3(blocks_for(C * krs)), dim3(NT), 0, s, w, Wm, g);
+  CHECK_LAUNCH(who);
+  // stride 1: backward-data is the correlation of gout, zero-padded by R-1-pad / S-1-pad, with the packed
+  // (flipped) weights: (ob, tj, ti, o2) ascending = the reference's (ob, oj, ki, o2) order
+  if (FPEMU_CONV_IMPLICIT && variant == 1 && stride == 1 && C % 64 == 0 && K % 64 == 0 && R - 1 - pad >= 0 &&
+      S - 1 - pad >= 0) {
+    rc = implicit_conv(who, gin, gout, Wm, nullptr, N, K, g.OH, g.OW, C, R, S, R - 1 - pad, S - 1 - pad, H, W, 1, cols,
+                       (int64_t)(ws_bytes / 4) - wf, s);
+    if (rc != 1) return rc;
+  }
+  if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   hipLaunchKernelGGL(fill_rows, dim3(blocks_for(N * C * HW)), dim3(NT), 0, s, gin, (const float *)nullptr, C, HW,
                      N * C * HW, 0);
   CHECK_LAUNCH(who);

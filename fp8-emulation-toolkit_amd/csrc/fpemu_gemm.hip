@@ -35,6 +35,9 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// a 16-byte vector that is only 4-byte aligned in memory: gfx950 global loads take it as one dwordx4
+// (the implicit-convolution operand: rows of the padded image shifted by the filter tap)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int BM = 128, BN = 128, BK = 16;  // VALU kernel: 128 x 128 x 16 tiles
 #ifndef FPEMU_GEMM_MBK
@@ -72,7 +75,7 @@ __device__ __forceinline__ void tile_coords(int h, int tid, int &r, int &k) {
   }
 }
 
-template <bool KCONT, bool FULL, int TBK, int ROWS>
+template <bool KCONT, bool FULL, int TBK, int ROWS, bool UNALIGNED = false>
 __device__ __forceinline__ void tile_load(const Operand &X, const float *base, int r0, int k0, int tid,
                                           f32x4 (&v)[TBK * ROWS / 1024]) {
 #pragma unroll
@@ -83,7 +86,8 @@ __device__ __forceinline__ void tile_load(const Operand &X, const float *base, i
     k += k0;
     if constexpr (FULL) {
       const float *src = KCONT ? base + (int64_t)r * X.ld + k : base + (int64_t)k * X.ld + r;
-      v[h] = *reinterpret_cast<const f32x4 *>(src);
+      if constexpr (UNALIGNED) v[h] = *reinterpret_cast<const f32x4u *>(src);
+      else v[h] = *reinterpret_cast<const f32x4 *>(src);
       continue;
     }
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -127,10 +131,13 @@ __device__ __forceinline__ void tile_ptrs(const Operand &X, int r0, int tid, con
     tp[h] = KCONT ? X.p + (int64_t)r * X.ld + k : X.p + (int64_t)k * X.ld + r;
   }
 }
-template <int NVEC>
+template <int NVEC, bool UNALIGNED = false>
 __device__ __forceinline__ void tile_load_ptrs(const float *const (&tp)[NVEC], int64_t uoff, f32x4 (&v)[NVEC]) {
 #pragma unroll
-  for (int h = 0; h < NVEC; h++) v[h] = *reinterpret_cast<const f32x4 *>(tp[h] + uoff);
+  for (int h = 0; h < NVEC; h++) {
+    if constexpr (UNALIGNED) v[h] = *reinterpret_cast<const f32x4u *>(tp[h] + uoff);
+    else v[h] = *reinterpret_cast<const f32x4 *>(tp[h] + uoff);
+  }
 }
 
 // Registers -> LDS image T[k][r].
@@ -333,11 +340,22 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 #ifndef FPEMU_GEMM_WAVES
 #define FPEMU_GEMM_WAVES 2
 #endif
-template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL, int TW>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FPEMU_GEMM_WAVES)))
-void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
-                                                       float alpha, float beta, int tiles_m, int tiles_n,
-                                                       Batch bt) {
+// Implicit convolution (fpemu_conv.hip): the GEMM's N index is a position q = oy * Wp + ox' of the PADDED-width
+// output grid of one image, so row (c, kj, ki) of the "gathered" operand is simply the padded image plane c
+// shifted by kj * Wp + ki -- contiguous memory, nothing to materialise.  The k loop walks segments (channel block,
+// kj, ki) of 64 channels each: B advances by 1 (next ki), Wp - (S-1) (next kj) or the channel-block step.
+// Columns with ox' >= OW (or q >= nvalid) are garbage positions: computed and dropped.  Accumulators start at
+// bias[row] (or +0) and C = acc, as in CHAIN mode.
+struct ConvMap {
+  const float *bias;  // nullptr: start at +0
+  int S, R, Wp;       // filter taps per row / rows, padded row pitch
+  int dk;             // +1: taps of a filter row walk right (forward); -1: left (backward-data: ki ascending = ox descending)
+  int OW, P, nvalid;  // valid columns per output row, output pixels per channel (C's row pitch), OH * Wp
+};
+
+template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL, int TW, bool CONV>
+__device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, int64_t ldc, float alpha, float beta,
+                                               int tiles_m, int tiles_n, Batch bt, const ConvMap &cm) {
   constexpr int TB = 64 * TW;  // block tile edge
   constexpr int LDT = ldt<TB>();
   constexpr int NV = MBK * TB / 1024;
@@ -362,7 +380,9 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         acc[i][j][r] = 0.f;
-        if constexpr (CHAIN) {
+        if constexpr (CONV) {
+          if (cm.bias != nullptr) acc[i][j][r] = cm.bias[m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk];
+        } else if constexpr (CHAIN) {
           const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int col = n0 + wn + j * 32 + li;
           if (row < A.R && col < B.R) acc[i][j][r] = C[(int64_t)row * ldc + col];
@@ -371,13 +391,32 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
 
   f32x4 pa[NV], pb[NV];
   const float *abase = A.p, *bbase = B.p;
+  [[maybe_unused]] int wki = 0, wkj = 0;  // CONV: filter tap of the current k segment
+  // next k segment: A by its segment stride; B by its segment stride, or (CONV) along the filter-tap walk
+  auto next_segment = [&]() {
+    abase += bt.ka;
+    if constexpr (CONV) {
+      int64_t inc = cm.dk;
+      if (++wki == cm.S) {
+        wki = 0;
+        inc = (int64_t)cm.Wp - cm.dk * (cm.S - 1);
+        if (++wkj == cm.R) {
+          wkj = 0;
+          inc = bt.kb - (int64_t)(cm.R - 1) * cm.Wp - cm.dk * (cm.S - 1);
+        }
+      }
+      bbase += inc;
+    } else {
+      bbase += bt.kb;
+    }
+  };
   const float *tpa[NV], *tpb[NV];  // FULL: per-thread pointers of the vectors of tile (segment 0, k0 = 0)
   if constexpr (FULL) {
     tile_ptrs<A_KCONT, MBK, TB>(A, m0, tid, tpa);
     tile_ptrs<B_KCONT, MBK, TB>(B, n0, tid, tpb);
   }
   tile_load<A_KCONT, FULL, MBK, TB>(A, abase, m0, 0, tid, pa);
-  tile_load<B_KCONT, FULL, MBK, TB>(B, bbase, n0, 0, tid, pb);
+  tile_load<B_KCONT, FULL, MBK, TB, CONV>(B, bbase, n0, 0, tid, pb);
   tile_store<A_KCONT, MBK, TB>(As[0], tid, pa);
   tile_store<B_KCONT, MBK, TB>(Bs[0], tid, pb);
   __syncthreads();
@@ -416,15 +455,14 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
     nk0 += MBK;
     if (nk0 >= K) {  // next k segment
       nk0 = 0;
-      abase += bt.ka;
-      bbase += bt.kb;
+      next_segment();
     }
     if constexpr (FULL && FPEMU_GEMM_PTRS) {
       tile_load_ptrs<NV>(tpa, (abase - A.p) + (A_KCONT ? (int64_t)nk0 : (int64_t)nk0 * A.ld), ra);
-      tile_load_ptrs<NV>(tpb, (bbase - B.p) + (B_KCONT ? (int64_t)nk0 : (int64_t)nk0 * B.ld), rb);
+      tile_load_ptrs<NV, CONV>(tpb, (bbase - B.p) + (B_KCONT ? (int64_t)nk0 : (int64_t)nk0 * B.ld), rb);
     } else {
       tile_load<A_KCONT, FULL, MBK, TB>(A, abase, m0, nk0, tid, ra);
-      tile_load<B_KCONT, FULL, MBK, TB>(B, bbase, n0, nk0, tid, rb);
+      tile_load<B_KCONT, FULL, MBK, TB, CONV>(B, bbase, n0, nk0, tid, rb);
     }
     fetched++;
   };
@@ -486,8 +524,7 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
       nk0 += MBK;
       if (nk0 >= K) {  // next k segment
         nk0 = 0;
-        abase += bt.ka;
-        bbase += bt.kb;
+        next_segment();
       }
       if constexpr (FULL && FPEMU_GEMM_PTRS) {  // uniform offsets (scalar arithmetic), one 64-bit add per vector
         tile_load_ptrs<NV>(tpa, (abase - A.p) + (A_KCONT ? (int64_t)nk0 : (int64_t)nk0 * A.ld), pa);
@@ -536,8 +573,7 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
       nk0 += MBK;
       if (nk0 >= K) {  // next k segment
         nk0 = 0;
-        abase += bt.ka;
-        bbase += bt.kb;
+        next_segment();
       }
       if constexpr (FULL && FPEMU_GEMM_PTRS) {  // uniform offsets (scalar arithmetic), one 64-bit add per vector
         tile_load_ptrs<NV>(tpa, (abase - A.p) + (A_KCONT ? (int64_t)nk0 : (int64_t)nk0 * A.ld), pa);
@@ -586,8 +622,24 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
 
 #endif
 
-  const int M = A.R, N = B.R;
-  if constexpr (CHAIN) {
+  [[maybe_unused]] const int M = A.R, N = B.R;
+  if constexpr (CONV) {
+#pragma unroll
+    for (int j = 0; j < TW; j++) {
+      const int q = n0 + wn + j * 32 + li;          // position in the padded-width output grid
+      const int oy = q / cm.Wp, ox = q - oy * cm.Wp;
+      if (q < cm.nvalid && ox < cm.OW) {
+        float *dst = C + (int64_t)oy * cm.OW + ox;
+#pragma unroll
+        for (int i = 0; i < TW; i++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            dst[(int64_t)row * cm.P] = acc[i][j][r];
+          }
+      }
+    }
+  } else if constexpr (CHAIN) {
 #pragma unroll
     for (int i = 0; i < TW; i++)
 #pragma unroll
@@ -621,6 +673,21 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc,
         }
       }
   }
+}
+
+template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL, int TW>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FPEMU_GEMM_WAVES)))
+void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc, float alpha, float beta, int tiles_m, int tiles_n,
+                      Batch bt) {
+  gemm_mfma_body<A_KCONT, B_KCONT, CHAIN, FULL, TW, false>(A, B, C, ldc, alpha, beta, tiles_m, tiles_n, bt, ConvMap{});
+}
+
+// The implicit convolution's form: A = packed weights [M][segments * 64] (k contiguous), B = padded image planes
+// ([64 channels][plane], positions contiguous), whole tiles only.
+template <int TW>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FPEMU_GEMM_WAVES)))
+void gemm_mfma_conv_kernel(Operand A, Operand B, float *C, int tiles_m, int tiles_n, Batch bt, ConvMap cm) {
+  gemm_mfma_body<true, false, true, true, TW, true>(A, B, C, 0, 1.0f, 0.0f, tiles_m, tiles_n, bt, cm);
 }
 
 typedef void (*mfma_fn_t)(Operand, Operand, float *, int64_t, float, float, int, int, Batch);
@@ -920,6 +987,31 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
 }
 
 }  // namespace
+
+// Internal to the library (fpemu_conv.hip): one implicit-convolution launch over `batch` images.
+//   out[b][m][oy][ox] = chain(bias[m]; for (cb, kj, ki, c2): Wm[m][((cb*R + kj)*S + ki)*64 + c2] *
+//                                                    xp[b][cb*64 + c2][oy + kj][ox + (reverse ? S-1-ki : ki)])
+// xp: zero-padded planes of Hp x Wp floats (plane = Hp * Wp), `cblocks` blocks of 64 channels per image, readable
+// for tile + (R-1)*Wp + S floats past the last plane.  M % 64 == 0.  Returns 0 or a hipError_t.
+extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float *xp, const float *bias, int64_t batch,
+                                       int64_t M, int64_t cblocks, int64_t R, int64_t S, int64_t plane, int64_t Wp,
+                                       int64_t OH, int64_t OW, int reverse, void *stream) {
+  const int64_t nvalid = OH * Wp, crs = cblocks * 64 * R * S;
+  const int64_t t128 = (M / 128) * ((nvalid + 127) / 128) * batch;
+  const int tb = (M % 128 == 0 && t128 >= 512) ? 128 : 64;
+  const int tiles_m = (int)(M / tb), tiles_n = (int)((nvalid + tb - 1) / tb);
+  Operand a, b;
+  a.p = Wm; a.ld = crs; a.R = (int)M; a.K = 64; a.vec = 1;
+  b.p = reverse ? xp + (S - 1) : xp; b.ld = plane; b.R = tiles_n * tb; b.K = 64; b.vec = 1;
+  Batch bt{0, cblocks * 64 * plane, M * OH * OW, 64, 64 * plane, (int)(cblocks * R * S)};
+  ConvMap cm{bias, (int)S, (int)R, (int)Wp, reverse ? -1 : 1, (int)OW, (int)(OH * OW), (int)nvalid};
+  const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)batch);
+  if (tb == 128)
+    hipLaunchKernelGGL(gemm_mfma_conv_kernel<2>, grid, dim3(NT), 0, (hipStream_t)stream, a, b, out, tiles_m, tiles_n, bt, cm);
+  else
+    hipLaunchKernelGGL(gemm_mfma_conv_kernel<1>, grid, dim3(NT), 0, (hipStream_t)stream, a, b, out, tiles_m, tiles_n, bt, cm);
+  return (int)hipGetLastError();
+}
 
 extern "C" int fpemu_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
                               int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans,

@@ -56,7 +56,12 @@ def test_conv_vs_reference_fixture(hip, bname, variant, fused):
 @pytest.mark.parametrize("case", [(2, 3, 32, 32, 64, 7, 7, 2, 3), (4, 64, 14, 14, 64, 3, 3, 1, 1),
                                   (3, 16, 9, 11, 24, 3, 3, 1, 1), (2, 128, 8, 8, 128, 1, 1, 2, 0),
                                   (1, 64, 28, 28, 192, 3, 3, 2, 1), (5, 1, 5, 5, 1, 5, 5, 1, 0),
-                                  (40, 64, 28, 28, 256, 3, 3, 1, 1)])   # >= 512 tiles: the 128 x 128 kernels
+                                  (40, 64, 28, 28, 256, 3, 3, 1, 1),    # >= 512 tiles: the 128 x 128 kernels
+                                  # the implicit-GEMM path (stride 1, 64-channel blocks): 1 x 1, 5 x 5, no padding
+                                  # (bp pads by R-1), rectangular images and filters, several channel blocks
+                                  (3, 128, 9, 13, 64, 1, 1, 1, 0), (2, 64, 12, 10, 128, 5, 5, 1, 2),
+                                  (2, 64, 10, 10, 64, 3, 3, 1, 0), (2, 64, 8, 8, 64, 3, 1, 1, 1),
+                                  (2, 192, 7, 7, 128, 3, 3, 1, 1), (33, 128, 56, 56, 128, 3, 3, 1, 1)])
 def test_conv_vs_oracle(hip, bname, variant, fused, case):
     """Batches with C or K < 64 included: every image is convolved (the reference collapses them)."""
     N, C, H, W, K, R, S, st, pd = case
@@ -73,6 +78,36 @@ def test_conv_vs_oracle(hip, bname, variant, fused, case):
     assert_bits_equal(gw, orc.conv2d_wu(go, x, (R, S), st, pd, fused), "%s %s wu" % (bname, case))
     y0, _, _ = _run_all(hip, x, w, None, go, st, pd, variant)
     assert_bits_equal(y0, orc.conv2d_fp(x, w, None, st, pd, fused), "no bias")
+
+
+def test_implicit_conv_small_workspace_chunks_and_fallback(hip):
+    """The implicit path with a workspace that holds the padded planes of two images only (chunked), and with one
+    too small for any padded image but big enough for the gathered form of one image... which is larger, so: the
+    smallest workspace the gathered form accepts still serves the implicit path.  Same bits every way."""
+    N, C, H, W, K, R, S, st, pd = 5, 64, 12, 12, 64, 3, 3, 1, 1
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((K, C, R, S)) * 0.2).astype(np.float32)
+    go = rng.standard_normal((N, K, H, W)).astype(np.float32)
+    L = hip.lib()
+    dims = (N, C, H, W, K, R, S, st, pd)
+    want_fp = orc.conv2d_fp(x, w, None, st, pd, True)
+    want_bp = orc.conv2d_bp(go, w, (H, W), st, pd, True)
+    tx, tw, tg = _t(x), _t(w), _t(go)
+    wf = K * C * R * S
+    two_padded = (wf + 2 * C * (H + 2) * (W + 2) + 128 + R * (W + 2) + S + 4) * 4
+    for nbytes in (L.fpemu_conv2d_workspace_bytes(0, *dims), L.fpemu_conv2d_workspace_bytes(0, 1, *dims[1:]),
+                   two_padded):
+        ws = torch.empty(nbytes // 4 + 4, device=DEV)
+        y = torch.empty(N, K, H, W, device=DEV)
+        gi = torch.empty(N, C, H, W, device=DEV)
+        assert L.fpemu_conv2d_fp_f32(y.data_ptr(), tx.data_ptr(), tw.data_ptr(), None, *dims, 1, ws.data_ptr(),
+                                     nbytes, None) == 0
+        assert L.fpemu_conv2d_bp_f32(gi.data_ptr(), tg.data_ptr(), tw.data_ptr(), *dims, 1, ws.data_ptr(), nbytes,
+                                     None) == 0
+        torch.cuda.synchronize()
+        assert_bits_equal(y.cpu().numpy(), want_fp, "implicit fp, workspace %d" % nbytes)
+        assert_bits_equal(gi.cpu().numpy(), want_bp, "implicit bp, workspace %d" % nbytes)
 
 
 def test_conv_small_workspace_chunks(hip):
