@@ -212,6 +212,92 @@ __global__ __launch_bounds__(NT) void pad_planes(const float *__restrict__ x, fl
   }
 }
 
+// Backward-data for very few input channels (the network's first layer: C = 3, 7 x 7, stride 2).  As a GEMM this
+// is a 3-row problem over a K*R*S x H*W gathered operand (20 GB for ResNet-50's first layer at batch 32); here a
+// lane owns ONE input pixel and its <= 4 channel chains and walks the reference's order (ob, oj ascending,
+// ki ascending, o2) directly, taking only the taps that exist (the reference does the same; a missing tap
+// contributes nothing).  Lanes of a wave hold pixels x = xi * stride + phase of one row and one phase, so which
+// (kj, ki) taps exist is uniform over the wave: the weights are scalar loads and gout is read coalesced.
+struct FewGeo {  // 32-bit throughout: one image's tensors are far below 2^31 elements
+  int st, pad, R, S, OH, OW, K, H, W, KB;
+};
+
+#ifndef FPEMU_FEW_ROWS
+#define FPEMU_FEW_ROWS 1
+#endif
+constexpr int kFewRows = FPEMU_FEW_ROWS;  // rows y, y + stride, ... per lane (they share the filter rows); measured on the first ResNet layer: 1 -> 1.69 ms, 2 -> 1.86, 4 -> 2.34 (too few waves left to hide the load latency)
+
+template <bool FUSED, int CC>
+__global__ __launch_bounds__(NT) void bp_few_channels(const float *__restrict__ go, const float *__restrict__ w,
+                                                      float *__restrict__ gin, FewGeo g) {
+  constexpr int TR = kFewRows;
+  const int st = g.st, pad = g.pad, R = g.R, S = g.S, OH = g.OH, OW = g.OW;
+  int by = blockIdx.y;
+  const int phase = by % st;  by /= st;        // x = xi * st + phase
+  const int r = by % st;                       // y = (yb * TR + t) * st + r
+  const int yb = by / st;
+  const int xi = blockIdx.x * blockDim.x + threadIdx.x, x = xi * st + phase;   // blockDim.x: 64 / 128 / 256
+  const int plane = OH * OW, RS = R * S, wstep = CC * RS;
+  float acc[TR][CC];
+#pragma unroll
+  for (int t = 0; t < TR; t++)
+#pragma unroll
+    for (int c = 0; c < CC; c++) acc[t][c] = 0.f;
+  // filter rows of these pixel rows: kj = (r + pad) mod st, + st, ... ; output row oj = yb*TR + t + (r + pad - kj) / st.
+  // The reference walks oj ascending = kj descending.
+  const int res = (r + pad) % st;
+  const int kjmax = R - 1 - ((R - 1 - res) % st + st) % st;
+  const float *gon = go + (int64_t)blockIdx.z * g.K * plane;
+  for (int ob = 0; ob < g.K; ob += g.KB)
+    for (int kj = kjmax; kj >= 0; kj -= st) {
+      const int ojb = yb * TR + (r + pad - kj) / st;   // exact: r + pad - kj is a multiple of st (may be negative)
+      for (int ki = 0; ki < S; ki++) {
+        const int d = phase + pad - ki;
+        const int dq = d / st;
+        if (dq * st != d) continue;                // uniform: this tap does not exist for this phase
+        const int oi = xi + dq;
+        if (!(x < g.W && oi >= 0 && oi < OW)) continue;   // per lane, once per tap
+        const float *wp = w + ((ob * CC * R + kj) * S + ki);
+        const float *sp = gon + ((ob * OH + ojb) * OW + oi);
+        bool okt[TR];
+#pragma unroll
+        for (int t = 0; t < TR; t++) okt[t] = ojb + t >= 0 && ojb + t < OH;   // uniform
+#pragma unroll 8
+        for (int o2 = 0; o2 < g.KB; o2++) {
+          float wv[CC];
+#pragma unroll
+          for (int c = 0; c < CC; c++) wv[c] = wp[o2 * wstep + c * RS];
+#pragma unroll
+          for (int t = 0; t < TR; t++) {
+            if (!okt[t]) continue;
+            const float gv = sp[o2 * plane + t * OW];
+#pragma unroll
+            for (int c = 0; c < CC; c++) {
+              if constexpr (FUSED) acc[t][c] = __builtin_fmaf(wv[c], gv, acc[t][c]);
+              else acc[t][c] = acc[t][c] + wv[c] * gv;   // -ffp-contract=off: product and sum rounded separately
+            }
+          }
+        }
+      }
+    }
+  if (x < g.W) {
+#pragma unroll
+    for (int t = 0; t < TR; t++) {
+      const int y = (yb * TR + t) * st + r;
+      if (y >= g.H) continue;
+      float *dst = gin + ((int64_t)blockIdx.z * CC * g.H + y) * g.W + x;
+#pragma unroll
+      for (int c = 0; c < CC; c++) dst[(int64_t)c * g.H * g.W] = acc[t][c];
+    }
+  }
+}
+
+typedef void (*bp_few_fn)(const float *, const float *, float *, FewGeo);
+template <bool FUSED> bp_few_fn pick_bp_few(int C) {
+  return C == 1 ? bp_few_channels<FUSED, 1> : C == 2 ? bp_few_channels<FUSED, 2>
+       : C == 3 ? bp_few_channels<FUSED, 3> : bp_few_channels<FUSED, 4>;
+}
+
 // out[n][k][p] = bias[k] (+0 when channel padding exists in the reference: turns a -0 bias into +0), or 0
 __global__ __launch_bounds__(NT) void fill_rows(float *__restrict__ out, const float *__restrict__ bias,
                                                 int64_t rows_per_img, int64_t P, int64_t total, int add_zero) {
@@ -304,6 +390,7 @@ int64_t implicit_floats(int64_t imgs, int64_t chans, int64_t Hp, int64_t Wp, int
 extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float *xp, const float *bias, int64_t batch,
                                        int64_t M, int64_t cblocks, int64_t R, int64_t S, int64_t plane, int64_t Wp,
                                        int64_t OH, int64_t OW, int reverse, void *stream);
+extern "C" int fpemu_gemm_conv_tile_(int64_t M, int64_t nvalid, int64_t batch);
 
 namespace {
 
@@ -315,6 +402,12 @@ int implicit_conv(const char *who, float *out, const float *src, const float *Wm
                   int64_t chans, int64_t Hs, int64_t Ws, int64_t M, int64_t R, int64_t S, int64_t ph, int64_t pw,
                   int64_t OH, int64_t OW, int reverse, float *xp, int64_t xp_floats, hipStream_t s) {
   const int64_t Hp = Hs + 2 * ph, Wp = Ws + 2 * pw;
+  // no padding (1 x 1 filters, ...) and whole tiles: the source planes ARE the operand, nothing is read past them
+  if (ph == 0 && pw == 0 && R == 1 && S == 1 && N <= 65535 && (OH * Wp) % fpemu_gemm_conv_tile_(M, OH * Wp, N) == 0) {
+    const int rc = fpemu_gemm_conv_launch_(out, Wm, src, bias, N, M, chans / 64, R, S, Hp * Wp, Wp, OH, OW, reverse, (void *)s);
+    if (rc != 0) return fail(who, rc, hipGetErrorString((hipError_t)rc));
+    return FPEMU_OK;
+  }
   int64_t chunk = N;
   while (chunk > 1 && implicit_floats(chunk, chans, Hp, Wp, R, S) > xp_floats) chunk = (chunk + 1) / 2;
   if (implicit_floats(chunk, chans, Hp, Wp, R, S) > xp_floats) return 1;
@@ -410,6 +503,18 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
   hipStream_t s = (hipStream_t)stream;
   float *Wm = (float *)ws, *cols = Wm + wf;
   const int64_t HW = H * W, krs = K * R * S, P = g.OH * g.OW;
+  if (C <= 4 && N <= 65535 && (H + stride) * stride <= 65535 && (variant == 0 || variant == 1) &&
+      K * g.OH * g.OW <= 0x7FFFFFFF && C * H * W <= 0x7FFFFFFF) {
+    const int64_t per_phase = (W + stride - 1) / stride;
+    const unsigned bs = per_phase <= 64 ? 64u : per_phase <= 128 ? 128u : (unsigned)NT;  // few idle lanes per row
+    const int64_t row_groups = ((H + stride - 1) / stride + kFewRows - 1) / kFewRows;   // per residue of y mod stride
+    const dim3 grid((unsigned)((per_phase + bs - 1) / bs), (unsigned)(row_groups * stride * stride), (unsigned)N);
+    const FewGeo fg{(int)stride, (int)pad, (int)R, (int)S, (int)g.OH, (int)g.OW, (int)K, (int)H, (int)W, (int)g.KB};
+    hipLaunchKernelGGL(variant == 1 ? pick_bp_few<true>((int)C) : pick_bp_few<false>((int)C), grid, dim3(bs), 0, s, gout, w,
+                       gin, fg);
+    CHECK_LAUNCH(who);
+    return FPEMU_OK;
+  }
   hipLaunchKernelGGL(pack_w_bp, dim3(blocks_for(C * krs)), dim3(NT), 0, s, w, Wm, g);
   CHECK_LAUNCH(who);
   // stride 1: backward-data is the correlation of gout, zero-padded by R-1-pad / S-1-pad, with the packed

@@ -993,12 +993,17 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
 //                                                    xp[b][cb*64 + c2][oy + kj][ox + (reverse ? S-1-ki : ki)])
 // xp: zero-padded planes of Hp x Wp floats (plane = Hp * Wp), `cblocks` blocks of 64 channels per image, readable
 // for tile + (R-1)*Wp + S floats past the last plane.  M % 64 == 0.  Returns 0 or a hipError_t.
+// Tile edge fpemu_gemm_conv_launch_ will pick (callers size the operand's read-ahead slack by it).
+extern "C" int fpemu_gemm_conv_tile_(int64_t M, int64_t nvalid, int64_t batch) {
+  const int64_t t128 = (M / 128) * ((nvalid + 127) / 128) * batch;
+  return (M % 128 == 0 && t128 >= 512) ? 128 : 64;
+}
+
 extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float *xp, const float *bias, int64_t batch,
                                        int64_t M, int64_t cblocks, int64_t R, int64_t S, int64_t plane, int64_t Wp,
                                        int64_t OH, int64_t OW, int reverse, void *stream) {
   const int64_t nvalid = OH * Wp, crs = cblocks * 64 * R * S;
-  const int64_t t128 = (M / 128) * ((nvalid + 127) / 128) * batch;
-  const int tb = (M % 128 == 0 && t128 >= 512) ? 128 : 64;
+  const int tb = fpemu_gemm_conv_tile_(M, nvalid, batch);
   const int tiles_m = (int)(M / tb), tiles_n = (int)((nvalid + tb - 1) / tb);
   Operand a, b;
   a.p = Wm; a.ld = crs; a.R = (int)M; a.K = 64; a.vec = 1;

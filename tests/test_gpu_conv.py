@@ -61,7 +61,10 @@ def test_conv_vs_reference_fixture(hip, bname, variant, fused):
                                   # (bp pads by R-1), rectangular images and filters, several channel blocks
                                   (3, 128, 9, 13, 64, 1, 1, 1, 0), (2, 64, 12, 10, 128, 5, 5, 1, 2),
                                   (2, 64, 10, 10, 64, 3, 3, 1, 0), (2, 64, 8, 8, 64, 3, 1, 1, 1),
-                                  (2, 192, 7, 7, 128, 3, 3, 1, 1), (33, 128, 56, 56, 128, 3, 3, 1, 1)])
+                                  (2, 192, 7, 7, 128, 3, 3, 1, 1), (33, 128, 56, 56, 128, 3, 3, 1, 1),
+                                  # few input channels: the direct backward-data kernel (phases of the stride)
+                                  (2, 4, 17, 19, 128, 3, 3, 1, 1), (3, 2, 20, 23, 16, 5, 5, 3, 2),
+                                  (1, 3, 64, 300, 64, 7, 7, 2, 3)])
 def test_conv_vs_oracle(hip, bname, variant, fused, case):
     """Batches with C or K < 64 included: every image is convolved (the reference collapses them)."""
     N, C, H, W, K, R, S, st, pd = case

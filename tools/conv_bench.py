@@ -7,6 +7,8 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fp8-emulation-toolkit_amd"))
 from mpemu.pytquant.hip import _binding as hip  # noqa: E402
 
+hip._SO = os.environ.get("FPEMU_LIB") or hip._SO  # tuning aid: a library built with other constants
+
 LAYERS = [(32, 3, 224, 224, 64, 7, 7, 2, 3), (32, 64, 56, 56, 64, 3, 3, 1, 1), (32, 128, 28, 28, 128, 3, 3, 1, 1),
           (32, 256, 14, 14, 256, 3, 3, 1, 1), (32, 512, 7, 7, 512, 3, 3, 1, 1), (32, 256, 56, 56, 64, 1, 1, 1, 0)]
 
