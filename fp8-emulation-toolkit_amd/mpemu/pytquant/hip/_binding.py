@@ -89,6 +89,37 @@ def lib():
     return _lib
 
 
+_ext = False  # not looked up yet
+
+
+def ext():
+    """The thin PyTorch-ROCm extension (_mpemu_torch.so, csrc/mpemu_torch.cpp) over the same C ABI: the
+    operator's two hot calls with checks, allocation, stream lookup and the straight-through autograd node in
+    C++.  None when it has not been built (or MPEMU_NO_TORCH_EXT=1): callers then take the ctypes path below --
+    the same library, the same bits, more host time per call."""
+    global _ext
+    if _ext is False:
+        _ext = None
+        if os.environ.get("MPEMU_NO_TORCH_EXT", "0") in ("", "0"):
+            lib()  # libfpemu_hip.so first: the extension links against it
+            try:
+                from . import _mpemu_torch
+                if _mpemu_torch.abi_version() == lib().fpemu_abi_version():
+                    _ext = _mpemu_torch
+            except ImportError:
+                _ext = None
+    return _ext
+
+
+def workspace_override():
+    """The scratch installed by use_workspace() on this thread, or None."""
+    return getattr(_tls, "ws", None)
+
+
+def tracing():
+    return _trace
+
+
 def _check(rc):
     if rc == 0:
         return

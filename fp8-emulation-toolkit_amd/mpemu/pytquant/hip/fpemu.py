@@ -24,6 +24,19 @@ set_rng_state = fpemu_hip.set_rng_state
 
 
 class FPEmuOp(Function):
+    @classmethod
+    def apply(cls, input, mode='NONE', inplace=False, scale=1.0, blocknorm=False, blocksize=1):
+        """Same call as the reference's FPEmuOp.apply.  A dense device tensor and a plain cast -- the case every
+        hook and emulator call is -- goes through the C++ extension (checks, allocation, launch and the
+        straight-through autograd node in one native call); everything else takes the Function below."""
+        ext = fpemu_hip.ext()
+        if (ext is not None and mode != 'NONE' and not blocknorm and input.is_cuda and not input.is_sparse
+                and not fpemu_hip.tracing()):
+            fmt, rmode = fpemu_hip.parse_mode(mode)
+            return ext.fpemu_op(input, bool(inplace), fmt, rmode, float(scale), fpemu_hip.get_rng_state()[0],
+                                fpemu_hip.next_offset(rmode))
+        return super().apply(input, mode, inplace, scale, blocknorm, blocksize)
+
     @staticmethod
     def forward(ctx, input, mode='NONE', inplace=False, scale=1.0, blocknorm=False, blocksize=1):
         if mode == 'NONE':

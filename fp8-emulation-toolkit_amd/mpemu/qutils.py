@@ -31,6 +31,7 @@ _FLT_MIN = {"e5m2": 1.5258789E-05, "e4m3": 1.9531250E-03, "e3m4": 1.5625000E-02,
 
 _amax_group = None
 _amax_elem_base = None
+_NO_SCALE_FMTS = (_hip.FMT_BF16, _hip.FMT_FP16, _hip.FMT_FP16_DAZ)  # their reference kernels take no scale
 
 
 def set_amax_process_group(group, elem_base=None):
@@ -286,6 +287,14 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
 
     if qtconfig.scaling is True:
         if qtconfig.scaling_method == "max" and on_device:
+            ext = _hip.ext()
+            if ext is not None and _amax_group is None and not _hip.tracing():
+                # amax -> device-side scale -> cast and the straight-through autograd node in one native call
+                fmt, rmode = _hip.parse_mode(mode)
+                if fmt not in _NO_SCALE_FMTS:
+                    return ext.quantize_per_tensor(tensor, bool(inplace), fmt, rmode, qtconfig.get_flt_max(), True,
+                                                   _hip.get_rng_state()[0], _hip.next_offset(rmode),
+                                                   _hip.workspace_override())
             return _ScaledCast.apply(tensor, mode, inplace, qtconfig.get_flt_max(), 0, True)
         scale = 1.0
         if qtconfig.scaling_method == "mean":

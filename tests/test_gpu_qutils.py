@@ -105,3 +105,47 @@ def test_half_and_bfloat16_tensors_through_qutils():
         s = orc.scale_from_amax(orc.amax(ref), 448.0)
         want = torch.from_numpy(orc.cast(ref, "E4M3_RNE", scale=s)).to(dt)
         assert torch.equal(q.cpu().view(torch.int16), want.view(torch.int16))
+
+
+def test_torch_extension_path_equals_ctypes_path(monkeypatch):
+    """FPEmuOp.apply / quantize_tensor go through _mpemu_torch.so (C++: checks, allocation, launch, autograd node)
+    when it is built, through ctypes otherwise: the same library underneath, so the same bits, call offsets and
+    gradients either way."""
+    from mpemu import qutils
+    from mpemu.pytquant import fpemu_cuda
+    from mpemu.pytquant.hip import _binding as hip
+
+    assert hip.ext() is not None, "_mpemu_torch.so is not built (make -C fp8-emulation-toolkit_amd/csrc)"
+    x = torch.from_numpy(mixed_inputs(70001, seed=4)).cuda()
+    x[~torch.isfinite(x)] = 0.5
+    results = {}
+    for use_ext in (True, False):
+        monkeypatch.setattr(hip, "_ext", hip.ext() if use_ext else None)
+        if not use_ext:
+            assert hip.ext() is None
+        hip.set_rng_state((99, 7))
+        out = []
+        out.append(fpemu_cuda.FPEmuOp.apply(x, "E4M3_RNE", False, 2.0))
+        out.append(fpemu_cuda.FPEmuOp.apply(x, "E5M2_STOCHASTIC", False, 1.0))            # offset 7
+        out.append(qutils.quantize_tensor(x, qutils.TensorQuantConfig("e4m3", "rne", "per-tensor"), None))
+        out.append(qutils.quantize_tensor(x, qutils.TensorQuantConfig("e5m2", "stochastic", "per-tensor"), None))  # 8
+        xi = x.clone()
+        r = fpemu_cuda.FPEmuOp.apply(xi, "E3M4_RNE", True, 1.0)
+        assert r is xi
+        out.append(xi)
+        nc = x.view(-1)[:70000].view(200, 350).t()                                        # non-contiguous input
+        out.append(fpemu_cuda.FPEmuOp.apply(nc, "E4M3_RNE", False, 1.0))
+        w = x.clone().requires_grad_(True)
+        y = fpemu_cuda.FPEmuOp.apply(w, "E4M3_RNE", False, 1.0)
+        q = qutils.quantize_tensor(y * 1.5, qutils.TensorQuantConfig("e4m3", "rne", "per-tensor"), None)
+        (q * 2.0).sum().backward()
+        out.append(w.grad.clone())
+        assert hip.get_rng_state() == (99, 9)
+        results[use_ext] = [t.detach().clone() for t in out]
+    for a, b in zip(results[True], results[False]):
+        assert a.shape == b.shape and torch.equal(a.contiguous().view(torch.int32), b.contiguous().view(torch.int32))
+    assert torch.equal(results[True][-1], torch.full_like(x, 3.0))                        # straight-through: 1.5 * 2
+    with pytest.raises(RuntimeError):
+        fpemu_cuda.FPEmuOp.apply(torch.zeros(4), "E4M3_RNE", False, 1.0)                  # CPU tensor: no CPU path
+    with pytest.raises(ValueError):
+        fpemu_cuda.FPEmuOp.apply(x, "E4M3_BOGUS", False, 1.0)
