@@ -85,6 +85,12 @@ class TensorQuantConfig(object):
 
         self.check_validity(dtype, scheme)
 
+    def __setattr__(self, name, value):
+        # any change of the configuration drops the cached dispatch plan of quantize_tensor
+        object.__setattr__(self, name, value)
+        if name != "_plan":
+            object.__setattr__(self, "_plan", None)
+
     def check_validity(self, dtype, scheme):
         if "int" in dtype:
             return  # integers of all sizes are acceptable
@@ -277,8 +283,40 @@ def _mean_scale(sample, qtconfig, threshold, use_mode):
     return 1.0 if scale < 1.0 else scale
 
 
+def _plan(qtconfig):
+    """(kind, mode, fmt, rmode, flt_max) of a configuration, computed once per configuration state (the hooks
+    call quantize_tensor tens to hundreds of times per step with the same few configurations):
+    kind 1 = per-tensor max scaling, 2 = plain cast, 0 = everything else (the general code below)."""
+    qtconfig.check_validity(qtconfig.dtype, qtconfig.scheme)
+    mode = qtconfig.dtype.upper()
+    if qtconfig.scheme is not None:
+        mode += "_" + qtconfig.scheme.upper()
+    kind, fmt, rmode = 0, -1, -1
+    if "INT" not in mode:
+        fmt, rmode = _hip.parse_mode(mode)
+        if qtconfig.scaling is True:
+            kind = 1 if (qtconfig.scaling_method == "max" and fmt not in _NO_SCALE_FMTS) else 0
+        elif not qtconfig.per_channel and not qtconfig.fine_grained:
+            kind = 2
+    plan = (kind, mode, fmt, rmode, qtconfig.get_flt_max())
+    qtconfig._plan = plan
+    return plan
+
+
 def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
     """Single entry point for quantising a tensor (qutils.py:264-345)."""
+    plan = getattr(qtconfig, "_plan", None) or _plan(qtconfig)
+    if plan[0] and tensor.is_cuda and _amax_group is None and not tensor.is_sparse:
+        ext = _hip.ext()
+        if ext is not None and not _hip.tracing():
+            # the two cases every hook call is: one native call does checks, allocation, launch(es) and the
+            # straight-through autograd node (csrc/mpemu_torch.cpp)
+            if plan[0] == 1:
+                return ext.quantize_per_tensor(tensor, bool(inplace), plan[2], plan[3], plan[4], True,
+                                               _hip.get_rng_state()[0], _hip.next_offset(plan[3]),
+                                               _hip.workspace_override())
+            return ext.fpemu_op(tensor, bool(inplace), plan[2], plan[3], 1.0, _hip.get_rng_state()[0],
+                                _hip.next_offset(plan[3]))
     qtconfig.check_validity(qtconfig.dtype, qtconfig.scheme)
     mode = qtconfig.dtype.upper()
     if qtconfig.scheme is not None:
