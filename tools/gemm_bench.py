@@ -7,16 +7,21 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fp8-emulation-toolkit_amd"))
 from mpemu.pytquant.hip import _binding as hip  # noqa: E402
 
-hip._SO = os.environ.get("FPEMU_LIB", hip._SO)  # tuning aid: a library built with other geometry constants
+hip._SO = os.environ.get("FPEMU_LIB") or hip._SO  # tuning aid: a library built with other geometry constants
 
 PEAK = {1: 157.3, 0: 78.6}
 
 
-def run(M, N, K, at, bt, variant, iters=5):
+ITERS = int(os.environ.get("GEMM_ITERS", "5"))   # short kernels: use 50+ so the clock ramp of the first launches washes out
+
+
+def run(M, N, K, at, bt, variant, iters=None):
+    iters = iters or ITERS
     A = torch.randn((K, M) if at else (M, K), device="cuda")
     B = torch.randn((N, K) if bt else (K, N), device="cuda")
     C = torch.zeros(M, N, device="cuda")
-    hip.gemm_(C, A, B, 1.0, at, bt, variant)
+    for _ in range(1 + iters // 5):
+        hip.gemm_(C, A, B, 1.0, at, bt, variant)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -1,0 +1,31 @@
+#!/bin/bash
+# SQ counters for the c-model GEMM kernels at 8192^3 (argument: v0 = VALU separate-rounding kernel, v1 = MFMA fmaf chain).
+# Two --pmc passes of at most 8 SQ counters each (rocprofv3 does not split counters over passes).
+set -o pipefail
+export TMPDIR=/tmp
+V=${1:-v0}
+OUT=gpurun_out/gemm_pmc_$V
+rm -rf $OUT; mkdir -p $OUT
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
+  --output-format csv -d $OUT/a -- python3 tools/gemm_bench.py 8192x8192x8192 nn $V > $OUT/a.log 2>&1 || { tail -5 $OUT/a.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE \
+  --output-format csv -d $OUT/b -- python3 tools/gemm_bench.py 8192x8192x8192 nn $V > $OUT/b.log 2>&1 || { tail -5 $OUT/b.log; exit 1; }
+grep -h "TFLOP" $OUT/a.log $OUT/b.log
+python3 - $OUT <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "gemm_" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+v = {k: sum(x) / len(x) for k, x in acc.items()}
+for k in sorted(v):
+    print("%-24s %.4g per launch (%d launches)" % (k, v[k], len(acc[k])))
+w = v.get("SQ_WAVE_CYCLES")
+if w:
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
+        if k in v:
+            print("%-24s %.1f %% of wave cycles" % (k, 100 * v[k] / w))
+if "SQ_LDS_IDX_ACTIVE" in v and v["SQ_LDS_IDX_ACTIVE"]:
+    print("LDS bank conflicts        %.2f %% of LDS-array cycles" % (100 * v.get("SQ_LDS_BANK_CONFLICT", 0) / v["SQ_LDS_IDX_ACTIVE"]))
+PY

@@ -139,6 +139,44 @@ __global__ __launch_bounds__(BLOCK) void k_pol(const u32x4 *in, u32x4 *out, uint
   else ST_ASM("sc0");
 }
 
+// Round-2 experiments.
+// E1: small workgroups with TWO adjacent vectors per lane in flight (no loop): group g owns vectors [g*2B, (g+1)*2B).
+template <int BLOCK, bool COMPUTE>
+__global__ __launch_bounds__(BLOCK) void k_pair(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
+  const uint64_t i = (uint64_t)blockIdx.x * (2 * BLOCK) + threadIdx.x;
+  if (i + BLOCK >= nvec) return;
+  const u32x4 a = __builtin_nontemporal_load(&in[i]);
+  const u32x4 b = __builtin_nontemporal_load(&in[i + BLOCK]);
+  u32x4 o = work<COMPUTE>(a, scale, rcp);
+  u32x4 *dst = out + i;
+  ST_ASM("sc1 nt\n\ts_nop 1");
+  o = work<COMPUTE>(b, scale, rcp);
+  dst = out + i + BLOCK;
+  ST_ASM("sc1 nt\n\ts_nop 1");
+}
+// E3: capped grid, software-pipelined loop: the NEXT vector's load is issued before (LOAD_FIRST) or after the
+// current vector's store.
+template <int BLOCK, bool LOAD_FIRST, bool COMPUTE>
+__global__ __launch_bounds__(BLOCK) void k_pipe(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
+  const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+  uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= nvec) return;
+  u32x4 cur = __builtin_nontemporal_load(&in[i]);
+  for (;;) {
+    const uint64_t nx = i + stride;
+    const bool more = nx < nvec;
+    u32x4 nxt = cur;
+    if (LOAD_FIRST && more) nxt = __builtin_nontemporal_load(&in[nx]);
+    u32x4 o = work<COMPUTE>(cur, scale, rcp);
+    u32x4 *dst = out + i;
+    ST_ASM("sc1 nt\n\ts_nop 1");
+    if (!LOAD_FIRST && more) nxt = __builtin_nontemporal_load(&in[nx]);
+    if (!more) break;
+    cur = nxt;
+    i = nx;
+  }
+}
+
 // Variant F: one lane handles vector i and vector i + nvec/2 (two distant regions in flight).
 template <bool COMPUTE>
 __global__ __launch_bounds__(256) void k_two(const u32x4 *in, u32x4 *out, uint64_t nvec, float scale, float rcp) {
@@ -253,6 +291,12 @@ int main(int argc, char **argv) {
   add("cast noloop U1 B128 builtin nt/nt", k_wave<128, 1, true, true, true>, 128, noloop(128, 1), 0);
   add("cast noloop U1 B64 builtin nt/nt", k_wave<64, 1, true, true, true>, 64, noloop(64, 1), 0);
   add("copy pol ld nt / st sc1nt", k_pol<1, 4, false>, 256, g1, 0);
+  add("E1 cast pair B64 (2 vec/lane)", k_pair<64, true>, 64, (int)(nvec / 128), 0);
+  add("E1 cast pair B128 (2 vec/lane)", k_pair<128, true>, 128, (int)(nvec / 256), 0);
+  add("E3 cast pipe B256 g2048 load-first", k_pipe<256, true, true>, 256, 2048, 0);
+  add("E3 cast pipe B256 g2048 store-first", k_pipe<256, false, true>, 256, 2048, 0);
+  add("E3 cast pipe B128 g8192 load-first", k_pipe<128, true, true>, 128, 8192, 0);
+  add("E3 cast pipe B128 g32768 load-first", k_pipe<128, true, true>, 128, 32768, 0);
   add("READ-only nt U1 (x2 scale)", k_read<true>, 256, g1, 0);
   add("amax B256 VPT8 cond (x2 scale)", k_amax<256, 8, true>, 256, noloop(256, 8), 0);
   hipEvent_t e0, e1;
