@@ -234,24 +234,26 @@ def main():
         step()
     barrier()
     torch.cuda.synchronize()
-    # The timed region: EXACTLY `steps` launches.  One HIP event after each launch, recorded on the stream
-    # the kernels run on (torch's current stream, which the binding passes to the C ABI): the wall clock gives
-    # `value`, the events give the dominant kernel's launch duration over the same launches (`roofline`).
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # The timed region: EXACTLY `steps` launches, back to back.  Two HIP events bracket them on the stream the kernels
+    # run on (torch's current stream, which the binding passes to the C ABI): the wall clock gives `value`, the events
+    # give the dominant kernel's average launch duration over the same launches (`roofline`).  (An event after every
+    # launch, as round 1 had it, puts a marker packet between consecutive kernels: ~1 % of a 0.31 ms launch.)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev[0].record()
+    ev0.record()
     for i in range(args.steps):
         step()
-        ev[i + 1].record()
+    ev1.record()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
     ms = reduce_max_f64((t1 - t0) * 1e3 / args.steps)
     value = world * n / (ms * 1e-3)
 
-    # roofline of the dominant kernel from the events of the timed region
-    per = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
-    avg_ms, min_ms = sum(per) / len(per), min(per)
+    # roofline of the dominant kernel from the events of the timed region; the fastest single launch from a short
+    # untimed pass with one event per launch
+    avg_ms = ev0.elapsed_time(ev1) / args.steps
+    _a, min_ms = time_launches(step, 10)
     achieved = BYTES_PER_ELEM * n / (avg_ms * 1e-3) / 1e9
     # HBM traffic from the committed PMC passes (profiles/pmc_traffic.json) -- reported only when they were
     # collected on THIS build of the library (sha256 of libfpemu_hip.so recorded beside them) and workload
@@ -271,7 +273,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "kernel": "cast_kernel<E4M3,RNE,f32>", "avg_launch_ms": round(avg_ms, 5),
                 "min_launch_ms": round(min_ms, 5), "algorithmic_bytes_per_launch": BYTES_PER_ELEM * n,
-                "timing": "HIP events on the launch stream, one per launch of the timed region"}
+                "timing": "two HIP events on the launch stream around the timed region's launches; min from 10 more launches, one event each"}
 
     extras = {}
     cpu_baseline = None
