@@ -169,7 +169,8 @@ struct DeviceScale {  // cast_kernel: scale given, or derived from a device word
       s = scale_from_amax(mx, rest->flt_max, clamp != 0);
       r = scale_reciprocal(s);
     } else if (amax_bits != nullptr) {
-      s = scale_from_amax(*amax_bits, rest->flt_max, clamp != 0);
+      // clamp == 2 (internal): the word is the scale itself, not an amax (fpemu_cast_device_scale)
+      s = clamp == 2 ? u2f(*amax_bits) : scale_from_amax(*amax_bits, rest->flt_max, clamp != 0);
       r = scale_reciprocal(s);
     }
   }
@@ -779,7 +780,25 @@ int fpemu_cast_scaled(const void *in, void *out, uint64_t n, int dtype, int fmt,
   prm.rcp = 1.f;
   prm.amax_bits = amax_bits;
   prm.rest.flt_max = flt_max;
-  prm.clamp = clamp;
+  prm.clamp = clamp ? 1 : 0;
+  prm.rest.seed = seed;
+  prm.rest.offset = offset;
+  prm.rest.elem_base = elem_base;
+  prm.rest.partials = nullptr;
+  prm.npart = 0;
+  prm.rest.amax_pub = nullptr;
+  return launch_cast(in, out, n, dtype, fmt, rmode, prm, stream);
+}
+
+int fpemu_cast_device_scale(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode, const float *scale,
+                            uint64_t seed, uint64_t offset, uint64_t elem_base, void *stream) {
+  if (scale == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast_device_scale: null scale");
+  CastParams prm;
+  prm.scale = 1.f;
+  prm.rcp = 1.f;
+  prm.amax_bits = reinterpret_cast<const uint32_t *>(scale);
+  prm.rest.flt_max = 0.f;
+  prm.clamp = 2;  // DeviceScale::resolve: the word is the scale
   prm.rest.seed = seed;
   prm.rest.offset = offset;
   prm.rest.elem_base = elem_base;
@@ -900,6 +919,23 @@ int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols,
                                     nullptr, 0, stream);
   if (rc == kNoRowsKernel)
     return fail(FPEMU_EINVAL, "fpemu_quantize_rows: format / rounding-mode pair takes no scale or is not defined");
+  return rc;
+}
+
+int fpemu_cast_rows_scaled(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt, int rmode,
+                           const float *scales, uint64_t seed, uint64_t offset, void *stream) {
+  if (rows == 0 || cols == 0) return FPEMU_OK;
+  if (in == nullptr || out == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast_rows_scaled: null buffer");
+  if (scales == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast_rows_scaled: null scales");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_cast_rows_scaled: bad dtype id");
+  if (rows > 0x7FFFFFFFull) return fail(FPEMU_EINVAL, "fpemu_cast_rows_scaled: more than 2^31-1 rows");
+  const unsigned es = elem_size(dtype);
+  if (((uintptr_t)in % es) || ((uintptr_t)out % es) || ((uintptr_t)scales % 4u))
+    return fail(FPEMU_EALIGN, "fpemu_cast_rows_scaled: buffer not aligned to its element size");
+  const int rc = fpemu_rows_launch_(in, out, rows, cols, dtype, fmt, rmode, 0.f, /*scale given*/ 3, seed, offset,
+                                    const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(scales)), 0, stream);
+  if (rc == kNoRowsKernel)
+    return fail(FPEMU_EINVAL, "fpemu_cast_rows_scaled: format / rounding-mode pair takes no scale or is not defined");
   return rc;
 }
 

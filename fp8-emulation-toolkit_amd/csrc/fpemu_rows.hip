@@ -7,6 +7,9 @@
 //   * the fine-grained loop over out_channels x groups (qutils.py:313-337) -- policy kRowsNoClamp;
 //   * block normalisation inside the native kernels (block_norm = true: cpp/fpemu_impl.cpp:778-815,
 //     :1149-1190, :1441-1478, :1734-1770, :1840-1860) -- policy kRowsBlockNorm, rows = blocks.
+// Policy kRowsGiven skips the reduction: the row's scale is read from a device array (the "mean" policies of
+// qutils.py:294-301, whose per-row statistic is torch.mode -- computed by torch, on the device, for all rows at
+// once -- and any other caller that already holds one scale per row in device memory).
 //
 // Team per row (TEAM): a 256-thread block; one wave64, four rows per block (rows of <= kWaveRowCols
 // elements: conv filters, block-norm blocks); or a single lane, 256 rows per block (rows of
@@ -29,7 +32,7 @@ using namespace fpemu;
 
 namespace {
 
-enum { kRowsNoClamp = 0, kRowsClamp = 1, kRowsBlockNorm = 2 };
+enum { kRowsNoClamp = 0, kRowsClamp = 1, kRowsBlockNorm = 2, kRowsGiven = 3 };
 constexpr uint64_t kWaveRowCols = 1024;
 constexpr uint64_t kLaneRowCols = 16;
 
@@ -49,7 +52,8 @@ template <int DT> __device__ __forceinline__ uint32_t drop_nan(uint32_t w) {
 template <int FMT, int RM, int DT, bool VEC, int TEAM>
 __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out_, uint64_t rows,
                                                       uint64_t cols, float flt_max, int policy,
-                                                      uint64_t seed, uint64_t offset, uint32_t *amax_out) {
+                                                      uint64_t seed, uint64_t offset, uint32_t *aux) {
+  // aux: kRowsGiven reads row r's scale (float bits) from aux[r]; otherwise, when not null, aux[r] receives the amax word
   constexpr unsigned V = Storage<DT>::V;
   constexpr bool SR = (RM == STOCHASTIC);
   static_assert(TEAM == 1 || TEAM == 64 || TEAM == kBlock, "team = lane, wave or block");
@@ -66,16 +70,17 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out
   u32x4 *vout = reinterpret_cast<u32x4 *>(eout);
   const uint64_t nvec = (VEC && TEAM != 1) ? cols / V : 0;  // a lone lane walks its short row by element
   const bool bn = (policy == kRowsBlockNorm);
+  const bool given = (policy == kRowsGiven);  // uniform over the launch
 
   uint32_t m = 0u;
-  for (uint64_t i = t; i < nvec; i += TS) {
+  for (uint64_t i = t; i < (given ? 0u : nvec); i += TS) {
     const u32x4 v = vin[i];
 #pragma unroll
     for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, bn ? drop_nan<DT>(v[j]) : v[j]);
   }
   // (a lone lane's loop is unit-stride: keep the loop vectoriser off it, it cannot select the result)
 #pragma clang loop vectorize(disable) interleave(disable)
-  for (uint64_t e = nvec * V + t; e < cols; e += TS) {
+  for (uint64_t e = nvec * V + t; e < (given ? 0u : cols); e += TS) {
     uint32_t w;
     if constexpr (DT == FPEMU_F32) w = f2u(ein[e]);
     else w = (uint32_t)ein[e];
@@ -93,8 +98,9 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out
   }
   if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
   else if constexpr (DT == FPEMU_BF16) r = r << 16;
-  if (amax_out != nullptr && t == 0) amax_out[row] = r;
-  const float scale = bn ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
+  if (aux != nullptr && !given && t == 0) aux[row] = r;
+  const float scale = given ? u2f(aux[row])
+                      : bn  ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
   const float rcp = scale_reciprocal(scale);
   const uint64_t roff = offset + row;
 
@@ -135,7 +141,7 @@ constexpr int kBigRegVecs = 16;
 template <int FMT, int RM, int DT, int NV, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *out_, uint64_t rows,
                                                          uint32_t nv, uint32_t lg, float flt_max, int policy,
-                                                         uint64_t seed, uint64_t offset, uint32_t *amax_out) {
+                                                         uint64_t seed, uint64_t offset, uint32_t *aux) {
   constexpr unsigned V = Storage<DT>::V;
   constexpr int kWaves = BLOCK / 64;
   const unsigned G = 1u << lg;
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *
   const u32x4 *vin = reinterpret_cast<const u32x4 *>(in_) + (live ? row : 0) * nv;
   u32x4 *vout = reinterpret_cast<u32x4 *>(out_) + row * nv;
   const bool bn = (policy == kRowsBlockNorm);
+  const bool given = (policy == kRowsGiven);  // uniform over the launch: scalar branches
 
   u32x4 v[NV];
 #pragma unroll
@@ -152,37 +159,42 @@ __global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *
     const uint32_t i = (uint32_t)k * G + t;
     v[k] = __builtin_nontemporal_load(&vin[i < nv ? i : 0u]);
   }
-  uint32_t m = 0u;
+  float scale;
+  if (given) {
+    scale = u2f(aux[live ? row : 0]);
+  } else {
+    uint32_t m = 0u;
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const bool ok = live && (uint32_t)k * G + t < nv;
-    uint32_t mk = 0u;
+    for (int k = 0; k < NV; k++) {
+      const bool ok = live && (uint32_t)k * G + t < nv;
+      uint32_t mk = 0u;
 #pragma unroll
-    for (int j = 0; j < 4; j++) mk = absmax_word<DT>(mk, bn ? drop_nan<DT>(v[k][j]) : v[k][j]);
-    mk = ok ? mk : 0u;
-    m = m > mk ? m : mk;
-  }
-  // butterfly over the row's lanes (G is uniform: scalar branches)
-#pragma unroll
-  for (unsigned off = 1; off < 64u; off <<= 1) {
-    if (off < G) {
-      const uint32_t o = (uint32_t)__shfl_xor((int)m, (int)off, 64);
-      m = m > o ? m : o;
+      for (int j = 0; j < 4; j++) mk = absmax_word<DT>(mk, bn ? drop_nan<DT>(v[k][j]) : v[k][j]);
+      mk = ok ? mk : 0u;
+      m = m > mk ? m : mk;
     }
-  }
-  uint32_t r = m;
-  if (G == (unsigned)BLOCK) {
-    __shared__ uint32_t part[kWaves];
-    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = r;
-    __syncthreads();
-    r = part[0];
+    // butterfly over the row's lanes (G is uniform: scalar branches)
 #pragma unroll
-    for (int w = 1; w < kWaves; w++) r = r > part[w] ? r : part[w];
+    for (unsigned off = 1; off < 64u; off <<= 1) {
+      if (off < G) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)m, (int)off, 64);
+        m = m > o ? m : o;
+      }
+    }
+    uint32_t r = m;
+    if (G == (unsigned)BLOCK) {
+      __shared__ uint32_t part[kWaves];
+      if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = r;
+      __syncthreads();
+      r = part[0];
+#pragma unroll
+      for (int w = 1; w < kWaves; w++) r = r > part[w] ? r : part[w];
+    }
+    if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
+    else if constexpr (DT == FPEMU_BF16) r = r << 16;
+    if (aux != nullptr && t == 0u && live) aux[row] = r;
+    scale = bn ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
   }
-  if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
-  else if constexpr (DT == FPEMU_BF16) r = r << 16;
-  if (amax_out != nullptr && t == 0u && live) amax_out[row] = r;
-  const float scale = bn ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
   const float rcp = scale_reciprocal(scale);
   const uint64_t roff = offset + row;
 
@@ -241,7 +253,7 @@ template <int BLOCK> rows_reg_fn pick_rows_big(int dtype, uint32_t per_lane, int
 template <int FMT, int RM, int DT>
 __global__ __launch_bounds__(kBlock) void rows_subvec_kernel(const void *in_, void *out_, uint64_t nvec,
                                                              uint32_t bs, float flt_max, int policy,
-                                                             uint64_t seed, uint64_t offset) {
+                                                             uint64_t seed, uint64_t offset, const uint32_t *aux) {
   constexpr unsigned V = Storage<DT>::V;
   constexpr bool SR = (RM == STOCHASTIC);
   const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -274,22 +286,24 @@ __global__ __launch_bounds__(kBlock) void rows_subvec_kernel(const void *in_, vo
     m[e] = r;
   }
   float y[V];
+  const unsigned lgbs = (unsigned)__builtin_ctz(bs);  // bs divides V: a power of two
   Philox4 blk_noise = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (unsigned e = 0; e < V; e++) {
     uint32_t r = m[e];
     if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
     else if constexpr (DT == FPEMU_BF16) r = r << 16;
-    const float scale = bn ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
-    const float rcp = scale_reciprocal(scale);
     const uint64_t g = idx * V + e;  // global element
+    const float scale = policy == kRowsGiven ? u2f(aux[g >> lgbs])
+                        : bn                 ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
+    const float rcp = scale_reciprocal(scale);
     uint32_t rnd = 0u;
     if constexpr (SR) {
       // element c of a block this short is byte c * NB of the block's first Philox draw (rand_bits_elem with
       // idx = c < V: superblock 0, lane 0, slot 0): one draw per block, not per element
       constexpr unsigned NB = noise_bytes<FMT>();
       const unsigned c = e & (bs - 1u);
-      if (c == 0u) blk_noise = philox4x32_10(seed, 0u, offset + g / bs);  // e, bs uniform: scalar branch
+      if (c == 0u) blk_noise = philox4x32_10(seed, 0u, offset + (g >> lgbs));  // e, bs uniform: scalar branch
       const unsigned pos = c * NB;
       rnd = (philox_word(blk_noise, pos / 4u) >> ((pos % 4u) * 8u)) & (NB == 2 ? 0xFFFFu : 0xFFu);
     }
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void rows_subvec_kernel(const void *in_, vo
   store_stream(reinterpret_cast<u32x4 *>(out_) + idx, o);
 }
 
-typedef void (*rows_subvec_fn)(const void *, void *, uint64_t, uint32_t, float, int, uint64_t, uint64_t);
+typedef void (*rows_subvec_fn)(const void *, void *, uint64_t, uint32_t, float, int, uint64_t, uint64_t, const uint32_t *);
 
 template <int DT> rows_subvec_fn pick_rows_subvec(int fmt, int rm) {
 #define FPEMU_CASE(F, R) \
@@ -351,13 +365,14 @@ template <int DT> rows_fn pick_rows_dt(bool vec, int team, int fmt, int rm) {
 
 // Internal to the library (declared in fpemu_hip.hip).  Arguments are validated by the callers except
 // for what depends on the kernel choice.  force_block: always one block per row (the per-tensor small
-// path: one row of up to 32 Ki elements).
+// path: one row of up to 32 Ki elements).  amax_out: policy 3 (kRowsGiven) READS one float scale per row from it;
+// the other policies write the row's amax word there when it is not null.
 extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype,
                                   int fmt, int rmode, float flt_max, int policy, uint64_t seed,
                                   uint64_t offset, uint32_t *amax_out, int force_block, void *stream) {
   const unsigned ve = vec_elems(dtype);
   // blocks shorter than a vector: the flat cast's geometry with a scale per element
-  if (cols < ve && (ve % cols) == 0 && amax_out == nullptr && (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 &&
+  if (cols < ve && (ve % cols) == 0 && (amax_out == nullptr || policy == kRowsGiven) && (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 &&
       ((rows * cols) % ve) == 0) {
     rows_subvec_fn sf = dtype == FPEMU_F32 ? pick_rows_subvec<FPEMU_F32>(fmt, rmode)
                       : dtype == FPEMU_F16 ? pick_rows_subvec<FPEMU_F16>(fmt, rmode)
@@ -370,7 +385,7 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
       return FPEMU_EINVAL;
     }
     hipLaunchKernelGGL(sf, dim3((unsigned)nblk), dim3(kBlock), 0, (hipStream_t)stream, in, out, nvec, (uint32_t)cols,
-                       flt_max, policy, seed, offset);
+                       flt_max, policy, seed, offset, (const uint32_t *)amax_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
       fpemu_set_error_(hipGetErrorString(e));

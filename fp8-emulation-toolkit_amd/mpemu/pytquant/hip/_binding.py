@@ -62,6 +62,10 @@ def lib():
         L.fpemu_quantize_per_tensor_ws.argtypes = [vp, vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, u64, vp]
         L.fpemu_quantize_per_tensor_static.restype = i32
         L.fpemu_quantize_per_tensor_static.argtypes = [vp, vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, vp]
+        L.fpemu_cast_device_scale.restype = i32
+        L.fpemu_cast_device_scale.argtypes = [vp, vp, u64, i32, i32, i32, vp, u64, u64, u64, vp]
+        L.fpemu_cast_rows_scaled.restype = i32
+        L.fpemu_cast_rows_scaled.argtypes = [vp, vp, u64, u64, i32, i32, i32, vp, u64, u64, vp]
         L.fpemu_quantize_rows.restype = i32
         L.fpemu_quantize_rows.argtypes = [vp, vp, u64, u64, i32, i32, i32, f32, i32, u64, u64, vp]
         i64 = ctypes.c_int64
@@ -83,7 +87,7 @@ def lib():
         L.fpemu_quantize_blocks.argtypes = [vp, vp, u64, u64, i32, i32, i32, u64, u64, vp]
         L.fpemu_cast_multi.restype = i32
         L.fpemu_cast_multi.argtypes = [vp, u64, i32, i32, i32, f32, u64, u64, vp]
-        if L.fpemu_abi_version() != 6:
+        if L.fpemu_abi_version() != 7:
             raise ImportError("libfpemu_hip.so: ABI version mismatch")
         _lib = L
     return _lib
@@ -311,6 +315,43 @@ def cast_scaled_(src, dst, fmt, rmode, amax_bits, flt_max, clamp=True, seed=None
         _check(lib().fpemu_cast_scaled(src.data_ptr(), dst.data_ptr(), src.numel(), _dtype_id(src), fmt,
                                        rmode, amax_bits.data_ptr(), float(flt_max), int(bool(clamp)),
                                        _seed if seed is None else seed, offset, elem_base, _stream(src)))
+    return dst
+
+
+def _require_scales(scales, like, count):
+    if (not torch.is_tensor(scales) or scales.device != like.device or scales.dtype != torch.float32
+            or not scales.is_contiguous() or scales.numel() < count):
+        raise ValueError("fpemu: scales must be a contiguous float32 tensor of at least %d element(s) on %s"
+                         % (count, like.device))
+
+
+def cast_device_scale_(src, dst, fmt, rmode, scale, seed=None, offset=None, elem_base=0):
+    """Cast with the scale read on the device from scale[0] (float32 tensor), no host sync."""
+    _require_device(src)
+    _require_device(dst, "output")
+    _require_scales(scale, src, 1)
+    if offset is None:
+        offset = _next_offset(rmode)
+    with _range("fpemu::cast_device_scale"), _on_device(src):
+        _check(lib().fpemu_cast_device_scale(src.data_ptr(), dst.data_ptr(), src.numel(), _dtype_id(src), fmt, rmode,
+                                             scale.data_ptr(), _seed if seed is None else seed, offset, elem_base,
+                                             _stream(src)))
+    return dst
+
+
+def cast_rows_scaled_(src, dst, rows, fmt, rmode, scales):
+    """Cast of a contiguous buffer viewed as [rows, numel/rows] with scales[r] (float32, device) for row r, one
+    launch; equals a loop of per-row casts with consecutive call offsets."""
+    _require_device(src)
+    _require_device(dst, "output")
+    n = src.numel()
+    if rows <= 0 or n % rows:
+        raise ValueError("fpemu: %d elements do not split into %d rows" % (n, rows))
+    _require_scales(scales, src, rows)
+    off = _take_offsets(rows) if rmode == STOCHASTIC else _offset
+    with _range("fpemu::cast_rows_scaled"), _on_device(src):
+        _check(lib().fpemu_cast_rows_scaled(src.data_ptr(), dst.data_ptr(), rows, n // rows, _dtype_id(src), fmt,
+                                            rmode, scales.data_ptr(), _seed, off, _stream(src)))
     return dst
 
 

@@ -267,9 +267,54 @@ def _hip_quantize_rows(src, dst, fmt, rmode, flt_max, rows, clamp):
         _hip.cast_scaled_(s2[r], d2[r], fmt, rmode, ws[r:r + 1], flt_max, clamp=clamp)
 
 
+def _device_mean_scales(stat, flt_min, threshold):
+    """float32 scales from the statistics `stat` (one element per scale) by the reference's rule
+    (qutils.py:278-281 / :298-301), as elementwise torch ops on the device -- the same operations, in the same
+    order and dtype, that the reference applies to its 0-d tensor (`flt_min / tensor` is torch's
+    reciprocal-then-multiply in both), so each element equals the scale the host-side loop would compute."""
+    a = abs(stat)
+    big = a > threshold
+    scale = flt_min / a
+    scale = torch.where(big, scale, 1.0)       # below the threshold (or NaN): mean := flt_min, scale = 1
+    scale = torch.where(scale < 1.0, 1.0, scale)
+    return scale.float().contiguous()
+
+
+class _GivenScaleCast(torch.autograd.Function):
+    """Cast with scale(s) already in device memory: `rows` = 0 one scale for the tensor, else one per row of the
+    [rows, cols] view.  Straight-through backward, as FPEmuOp (pytquant/cpp/fpemu.py:68-71)."""
+
+    @staticmethod
+    def forward(ctx, tensor, mode, inplace, scales, rows):
+        fmt, rmode = _hip.parse_mode(mode)
+        src = tensor.contiguous()
+        dst = src if inplace else torch.empty_like(src)
+        if fmt in _NO_SCALE_FMTS:
+            _hip.cast_(src, dst, fmt, rmode)  # these formats take no scale (cpp/fpemu_impl.cpp:1933-1957)
+        elif not rows:
+            _hip.cast_device_scale_(src, dst, fmt, rmode, scales)
+        elif rows >= 64 or src.numel() // rows <= (1 << 16):
+            _hip.cast_rows_scaled_(src, dst, rows, fmt, rmode, scales)
+        else:  # a few very long rows: full-width launches, row by row (see _hip_quantize_rows)
+            s2, d2 = src.view(rows, -1), dst.view(rows, -1)
+            for r in range(rows):
+                _hip.cast_device_scale_(s2[r], d2[r], fmt, rmode, scales[r:r + 1])
+        if inplace:
+            if src is not tensor:
+                tensor.copy_(src)
+            ctx.mark_dirty(tensor)
+            return tensor
+        return dst
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None, None, None, None
+
+
 def _mean_scale(sample, qtconfig, threshold, use_mode):
     """The reference's "mean" policies, host-synchronising like the original
-    (qutils.py:276-281 per tensor; :294-301 / :322-327 per channel / group use torch.mode)."""
+    (qutils.py:276-281 per tensor; :294-301 / :322-327 per channel / group use torch.mode).  Used where the
+    device-side forms above do not apply (CPU tensors for the INT modes, ragged fine-grained groups)."""
     flat = torch.flatten(sample.detach())
     if use_mode:
         mean = abs(torch.mode(flat).values.data)
@@ -336,6 +381,14 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
             return _ScaledCast.apply(tensor, mode, inplace, qtconfig.get_flt_max(), 0, True)
         scale = 1.0
         if qtconfig.scaling_method == "mean":
+            if on_device and tensor.numel() > 0:
+                if _amax_group is not None:
+                    raise NotImplementedError("per-tensor-mean scaling of a sharded tensor: the mean is not reduced "
+                                              "over the amax process group")
+                # the statistic and the scale rule stay torch ops on the device; the cast reads the scale there
+                mean = torch.mean(abs(torch.flatten(tensor.detach())))
+                scales = _device_mean_scales(mean.reshape(1), qtconfig.get_flt_min(), 1e-5)
+                return _GivenScaleCast.apply(tensor, mode, inplace, scales, 0)
             scale = _mean_scale(tensor, qtconfig, 1e-5, use_mode=False)
         elif qtconfig.scaling_method == "max":
             vmax = torch.max(abs(torch.flatten(tensor.detach())))
@@ -347,6 +400,14 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
         if qtconfig.scaling_method == "max" and on_device and tensor.dim() >= 1 and tensor.shape[0] > 0:
             # the reference loops over dim 0 and never goes through autograd for the pieces
             q = _ScaledCast.apply(tensor.detach(), mode, inplace, qtconfig.get_flt_max(), tensor.shape[0], True)
+            return tensor if inplace else q
+        if (qtconfig.scaling_method == "mean" and on_device and tensor.dim() >= 1 and tensor.shape[0] > 0
+                and tensor.numel() > 0):
+            # torch.mode of every row in one call, the scale rule elementwise, one cast launch for all rows
+            rows = tensor.shape[0]
+            flat = tensor.detach().contiguous().view(rows, -1)
+            scales = _device_mean_scales(torch.mode(flat, dim=1).values, qtconfig.get_flt_min(), 1e-6)
+            q = _GivenScaleCast.apply(tensor.detach(), mode, inplace, scales, rows)
             return tensor if inplace else q
         tensor_q = None if inplace else torch.zeros_like(tensor)
         for c in range(tensor.shape[0]):

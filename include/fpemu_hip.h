@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FPEMU_ABI_VERSION 6
+#define FPEMU_ABI_VERSION 7
 
 /* Storage dtype of in/out buffers. */
 enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
@@ -133,6 +133,14 @@ int fpemu_cast_scaled(const void *in, void *out, uint64_t n, int dtype, int fmt,
                       const uint32_t *amax_bits, float flt_max, int clamp, uint64_t seed,
                       uint64_t offset, uint64_t elem_base, void *stream);
 
+/* Cast with the scale itself read ON DEVICE from *scale (one fp32 word, read in stream order; no host sync).
+ * For the per-tensor "mean" policy of quantize_tensor (qutils.py:276-281, 287), whose statistic -- torch.mean --
+ * and scale arithmetic stay torch ops on the device, and for any caller that already holds its scale in device
+ * memory.  Identical to fpemu_cast(..., scale = *scale, ...) except that the scale is not checked: a zero,
+ * infinite or NaN word gives what the arithmetic gives (the reference checks nothing either). */
+int fpemu_cast_device_scale(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode, const float *scale,
+                            uint64_t seed, uint64_t offset, uint64_t elem_base, void *stream);
+
 /* quantize_tensor's per-tensor "max" branch in one call (qutils.py:282-287; clamp=0 gives the
  * fine-grained branch's unclamped scale, qutils.py:328-332): zero the workspace word, amax,
  * device-side scale, cast.  amax_ws: 4 bytes of device memory owned by the caller (holds the
@@ -181,6 +189,15 @@ int fpemu_quantize_per_tensor_static(const void *in, void *out, uint64_t n, int 
 int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt,
                         int rmode, float flt_max, int clamp, uint64_t seed, uint64_t offset,
                         void *stream);
+
+/* Cast of a contiguous [rows, cols] buffer with one scale PER ROW read from device memory (scales[r], fp32), one
+ * launch.  Replaces the loop of per-channel casts of quantize_tensor's "mean" policy (qutils.py:289-311 with
+ * :294-301: per row a torch.mode, a host-synchronising scale computation and one cast launch): the caller computes
+ * all rows' scales with torch ops on the device and passes the array.  Results equal a loop of
+ * fpemu_cast(row r, scale = scales[r], offset = offset + r) over the rows.  Scales are not checked (see
+ * fpemu_cast_device_scale).  Formats without a scale (BF16 / FP16) are rejected. */
+int fpemu_cast_rows_scaled(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt, int rmode,
+                           const float *scales, uint64_t seed, uint64_t offset, void *stream);
 
 /* Block-normalised cast: the reference's forward(..., block_norm = true, block_size) for the formats
  * whose kernels have that branch (E5M2_Kernel cpp/fpemu_impl.cpp:778-815, E4M3_Kernel :1149-1190,

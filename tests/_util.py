@@ -7,6 +7,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 FLT_MAX = {"E5M2": 57344.0, "E4M3": 448.0, "E3M4": 30.0}
+FLT_MIN = {"E5M2": 1.5258789E-05, "E4M3": 1.9531250E-03, "E3M4": 1.5625000E-02}  # reference qutils.py get_flt_min
 
 DET_MODES = ["E5M2_RNE", "E4M3_RNE", "E3M4_RNE", "E5M2_RTZ", "E5M2_RNAZ", "E5M2_RNTZ", "E5M2_RPINF",
              "E5M2_RNINF", "E5M2_DAZ_RNE", "E5M2_DAZ_RNAZ", "E5M2_DAZ_RNTZ", "BFLOAT16_RNE",

@@ -193,6 +193,13 @@ def gen_qtensor():
         "conv": torch.randn(6, 4, 3, 3, generator=g) * 0.2,
         "odd": torch.randn(7, 13, generator=g) * 5.0,
     }
+    # rows with ONE most frequent value each (torch.mode is what the per-channel "mean" policy reads,
+    # qutils.py:297; with all-distinct values its result is a tie-break that differs between devices)
+    modal = torch.randn(24, 40, generator=g)
+    for r, v in enumerate([0.0, 1e-7, -1e-7, 3e-6, 1e-5, -2e-5, 1e-4, 1.5258789e-05, 0.5, -0.003, 7.0, 1e-3,
+                           float("inf"), 2e-6, 9e-7, 1.1e-6, -4e-4, 6e-5, 3e-5, 1.0, 5e-6, -8e-6, 2.5e-4, 1e-6]):
+        modal[r, r % 7:r % 7 + 12] = v
+    tensors["modal"] = modal
     cases = [
         ("e4m3", "rne", "per-tensor", 1), ("e5m2", "rne", "per-tensor", 1),
         ("e3m4", "rne", "per-tensor", 1), ("e4m3", "rne", "per-channel", 1),
@@ -200,13 +207,17 @@ def gen_qtensor():
         ("e4m3", "rne", "per-tensor-mean", 1), ("e4m3", "rne", "None", 1),
         ("e5m2", "rtz", "None", 1), ("e4m3", "rne", "fine-grained", 8),
         ("e3m4", "rne", "fine-grained", 4),
+        ("e5m2", "rne", "per-channel-mean", 1), ("e4m3", "rne", "per-channel-mean", 1),
+        ("e5m2", "rne", "per-tensor-mean", 1),
     ]
     out = {}
     names = []
     for tname, t in tensors.items():
         out["in/" + tname] = t.numpy().view(np.uint32)
         for dtype, scheme, scaling, gs in cases:
-            if scaling == "fine-grained" and (t.dim() < 2 or tname == "zeros"):
+            if scaling == "fine-grained" and (t.dim() < 2 or tname in ("zeros", "modal")):  # all-zero group: inf scale, exit()
+                continue
+            if scaling == "per-channel-mean" and tname not in ("modal", "zeros"):
                 continue
             cfg = qutils.TensorQuantConfig(dtype, scheme, scaling, gs)
             for inplace in (False, True):

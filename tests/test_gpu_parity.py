@@ -350,6 +350,78 @@ def test_rows_kernel_16bit_storage(hip, dt):
             assert torch.equal(o[r].cpu().view(torch.int16), want.view(torch.int16)), (dt, rows, cols, r)
 
 
+@pytest.mark.parametrize("mode", ["E5M2_RNE", "E4M3_STOCHASTIC", "E3M4_RTZ"])
+@pytest.mark.parametrize("rows,cols", [(64, 1), (32, 2), (16, 4), (7, 13), (40, 64), (33, 768), (9, 4096), (5, 11008),
+                                       (3, 16384), (3, 40001), (2, 65536), (300, 100)])
+def test_cast_rows_scaled_vs_oracle_loop(hip, rows, cols, mode):
+    """fpemu_cast_rows_scaled (one scale per row from device memory) = a loop of per-row casts with
+    consecutive call offsets (reference qutils.py:289-311 with the scale of :294-301), every kernel form."""
+    fmt, rm = hip.parse_mode(mode)
+    rng = np.random.default_rng(rows * 977 + cols)
+    x = (rng.standard_normal((rows, cols)) * np.exp(rng.standard_normal((rows, 1)) * 3)).astype(np.float32)
+    sc = np.exp(rng.standard_normal(rows) * 3).astype(np.float32)
+    sc[0] = 1.0
+    t = torch.from_numpy(x).to(DEV)
+    scales = torch.from_numpy(sc).to(DEV)
+    o = torch.empty_like(t)
+    hip.set_rng_state((31, 500))
+    hip.cast_rows_scaled_(t, o, rows, fmt, rm, scales)
+    got = o.cpu().numpy()
+    for r in range(rows):
+        want = orc.cast(x[r], mode, scale=float(sc[r]), seed=31, offset=500 + r)
+        assert_bits_equal(got[r], want, "%s row %d of %dx%d" % (mode, r, rows, cols), nan_payload_ok=True)
+    if rm == hip.STOCHASTIC:
+        assert hip.get_rng_state() == (31, 500 + rows)
+    # in place, and the scales untouched
+    hip.set_rng_state((31, 500))
+    hip.cast_rows_scaled_(t, t, rows, fmt, rm, scales)
+    assert torch.equal(t.view(torch.int32), o.view(torch.int32))
+    assert torch.equal(scales.cpu(), torch.from_numpy(sc))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_cast_rows_scaled_16bit_storage(hip, dt):
+    fmt, rm = hip.parse_mode("E4M3_RNE")
+    for rows, cols in ((16, 4), (9, 33), (40, 256), (6, 16392), (3, 65536)):
+        t = (torch.randn(rows, cols, device=DEV) * 3).to(dt)
+        sc = (torch.rand(rows, device=DEV) * 20 + 0.25).float()
+        o = torch.empty_like(t)
+        hip.cast_rows_scaled_(t, o, rows, fmt, rm, sc)
+        x = t.float().cpu().numpy()
+        for r in range(rows):
+            want = torch.from_numpy(orc.cast(x[r], "E4M3_RNE", scale=float(sc[r].item()))).to(dt)
+            assert torch.equal(o[r].cpu().view(torch.int16), want.view(torch.int16)), (dt, rows, cols, r)
+
+
+@pytest.mark.parametrize("mode", ["E4M3_RNE", "E5M2_STOCHASTIC", "BFLOAT16_RNE"])
+@pytest.mark.parametrize("n", [1, 1000, 1 << 20, (1 << 20) + 3])
+def test_cast_device_scale_equals_host_scale(hip, mode, n):
+    """fpemu_cast_device_scale(*scale) = fpemu_cast(scale) bit for bit (incl. the noise stream and elem_base)."""
+    fmt, rm = hip.parse_mode(mode)
+    t = torch.randn(n, device=DEV) * 5
+    for sc in (1.0, 0.37, 4096.0, 3.0e-3):
+        a, b = torch.empty_like(t), torch.empty_like(t)
+        hip.cast_(t, a, fmt, rm, scale=sc, seed=9, offset=77, elem_base=4096)
+        hip.cast_device_scale_(t, b, fmt, rm, torch.tensor([sc], dtype=torch.float32, device=DEV), seed=9, offset=77,
+                               elem_base=4096)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (mode, n, sc)
+    assert_bits_equal(b.cpu().numpy()[:4096], orc.cast(t.cpu().numpy(), mode, scale=3.0e-3, seed=9, offset=77,
+                                                        elem_base=4096)[:4096], mode)
+
+
+def test_cast_rows_scaled_argument_errors(hip):
+    t = torch.randn(4, 8, device=DEV)
+    sc = torch.ones(4, device=DEV)
+    with pytest.raises(ValueError):  # BF16 takes no scale
+        hip.cast_rows_scaled_(t, torch.empty_like(t), 4, *hip.parse_mode("BFLOAT16_RNE"), sc)
+    with pytest.raises(ValueError):  # too few scales
+        hip.cast_rows_scaled_(t, torch.empty_like(t), 4, *hip.parse_mode("E4M3_RNE"), sc[:3])
+    with pytest.raises(ValueError):  # wrong dtype
+        hip.cast_rows_scaled_(t, torch.empty_like(t), 4, *hip.parse_mode("E4M3_RNE"), sc.double())
+    with pytest.raises(ValueError):  # host scales
+        hip.cast_device_scale_(t, torch.empty_like(t), *hip.parse_mode("E4M3_RNE"), torch.ones(1))
+
+
 def test_rows_kernel_rejects_scale_free_formats(hip):
     t = torch.randn(4, 8, device=DEV)
     fmt, rm = hip.parse_mode("BFLOAT16_RNE")

@@ -149,3 +149,58 @@ def test_torch_extension_path_equals_ctypes_path(monkeypatch):
         fpemu_cuda.FPEmuOp.apply(torch.zeros(4), "E4M3_RNE", False, 1.0)                  # CPU tensor: no CPU path
     with pytest.raises(ValueError):
         fpemu_cuda.FPEmuOp.apply(x, "E4M3_BOGUS", False, 1.0)
+
+
+def _host_loop_mean(qutils, tensor, cfg):
+    """The reference's loop (qutils.py:276-287 / 289-311), one host-synchronising scale and one cast per piece."""
+    mode = (cfg.dtype + "_" + cfg.scheme).upper()
+    if cfg.scaling:
+        return qutils.fpemu_device_fn(tensor.clone(), mode, inplace=False,
+                                      scale=qutils._mean_scale(tensor, cfg, 1e-5, use_mode=False))
+    out = torch.zeros_like(tensor)
+    for c in range(tensor.shape[0]):
+        sub = tensor.select(0, c).detach()
+        out.select(0, c).copy_(qutils.fpemu_device_fn(sub, mode, inplace=False,
+                                                      scale=qutils._mean_scale(sub, cfg, 1e-6, use_mode=True)))
+    return out
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("scaling", ["per-channel-mean", "per-tensor-mean"])
+@pytest.mark.parametrize("scheme", ["rne", "stochastic"])
+def test_mean_policies_device_side_equal_the_host_loop(scaling, scheme, dt):
+    """The "mean" policies with statistic, scale rule and cast all on the device (one torch.mode / torch.mean, one
+    launch) give the bits of the reference's loop run on the same device: all-distinct rows (torch.mode's
+    tie-break), repeated values, tiny and zero rows, conv-shaped and long rows."""
+    from mpemu import qutils
+    from mpemu.pytquant.hip import _binding as _h
+    g = torch.Generator(device=DEV).manual_seed(11)
+    shapes = [(24, 40), (6, 4, 3, 3), (70, 768), (5, 3000), (3, 20000)]
+    for shape in shapes:
+        x = torch.randn(*shape, device=DEV, generator=g)
+        x = (x * 16).round() / 16 if shape[0] % 2 == 0 else x      # grids: real modes; else all-distinct
+        x[0] = 0.0
+        x[1] = x[1] * 1e-7
+        x.view(shape[0], -1)[2, :3] = 2.5e-4
+        x = x.to(dt)
+        cfg = qutils.TensorQuantConfig("e5m2", scheme, scaling)
+        for inplace in (False, True):
+            _h.set_rng_state((3, 900))
+            want = _host_loop_mean(qutils, x, cfg)
+            used = _h.get_rng_state()
+            _h.set_rng_state((3, 900))
+            xin = x.clone()
+            got = qutils.quantize_tensor(xin, cfg, None, inplace=inplace)
+            assert _h.get_rng_state() == used, "call offsets consumed differ from the loop's"
+            assert torch.equal(got.view(torch.int16 if dt != torch.float32 else torch.int32),
+                               want.view(torch.int16 if dt != torch.float32 else torch.int32)), (shape, inplace)
+            assert (got.data_ptr() == xin.data_ptr()) == inplace
+
+
+def test_mean_policy_per_tensor_is_differentiable_ste():
+    from mpemu import qutils
+    x = torch.randn(64, 32, device=DEV, requires_grad=True)
+    cfg = qutils.TensorQuantConfig("e4m3", "rne", "per-tensor-mean")
+    y = qutils.quantize_tensor(x, cfg, None, inplace=False)
+    y.sum().backward()
+    assert torch.equal(x.grad, torch.ones_like(x))

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import orc
-from _util import DET_MODES, EXT_MODES, FLT_MAX, assert_bits_equal, bits, jload, npz
+from _util import DET_MODES, EXT_MODES, FLT_MAX, FLT_MIN, assert_bits_equal, bits, jload, npz
 
 
 def test_philox_known_answers():
@@ -206,6 +206,21 @@ def _restate_quantize_tensor(x, dtype, scheme, scaling, gs):
         out = np.empty_like(x)
         for c in range(x.shape[0]):
             out[c] = orc.cast(x[c], mode, scale=orc.scale_from_amax(orc.amax(x[c]), fmax))
+        return out
+    if scaling == "per-channel-mean":
+        # qutils.py:294-301: the statistic is torch.mode of the row; scale = flt_min / |mode| computed by torch as
+        # reciprocal-then-multiply in fp32, 1.0 when |mode| <= 1e-6 or when the quotient is below 1
+        fmin = np.float32(FLT_MIN[dtype.upper()])
+        out = np.empty_like(x)
+        for c in range(x.shape[0]):
+            vals, counts = np.unique(x[c], return_counts=True)
+            a = np.abs(np.float32(vals[np.argmax(counts)]))
+            s = np.float32(1.0)
+            if a > np.float32(1e-6):
+                with np.errstate(divide="ignore"):
+                    s = np.float32(np.float32(1.0) / a) * fmin
+                s = np.float32(1.0) if s < 1.0 else np.float32(s)
+            out[c] = orc.cast(x[c], mode, scale=float(s))
         return out
     if scaling == "fine-grained":
         out = np.empty_like(x)
