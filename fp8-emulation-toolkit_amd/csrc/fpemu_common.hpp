@@ -114,13 +114,38 @@ struct ElemNoise {
   __device__ __forceinline__ uint32_t pair(unsigned e) const { return one(e) | (one(e + 1u) << 16); }
 };
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t m) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64);
-    m = m > o ? m : o;
-  }
+// One step of an ASCENDING max butterfly: m <- max(m, m of the partner group of OFF lanes).  Before the step m is
+// uniform over aligned groups of OFF lanes (steps 1, 2, ... OFF/2 have run), so any lane of the partner group will do:
+// OFF 1 / 2 are quad permutes, OFF 4 / 8 the half-row / row mirrors (lane i <-> 7-i / 15-i lands in the partner
+// group) -- DPP modifiers on the v_max itself, no LDS crossbar round trip.  OFF 16 / 32 cross DPP rows: ds_bpermute.
+template <unsigned OFF> __device__ __forceinline__ uint32_t xor_max_step(uint32_t m) {
+  uint32_t o;
+  if constexpr (OFF == 1) o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+  else if constexpr (OFF == 2) o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  else if constexpr (OFF == 4) o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  else if constexpr (OFF == 8) o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xF, 0xF, false);  // row_mirror
+  else o = (uint32_t)__shfl_xor((int)m, (int)OFF, 64);
+  return m > o ? m : o;
+}
+
+// max over the aligned group of G lanes (G a power of two <= 64, uniform), result in every lane of the group
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t m, unsigned G) {
+  if (1u < G) m = xor_max_step<1>(m);
+  if (2u < G) m = xor_max_step<2>(m);
+  if (4u < G) m = xor_max_step<4>(m);
+  if (8u < G) m = xor_max_step<8>(m);
+  if (16u < G) m = xor_max_step<16>(m);
+  if (32u < G) m = xor_max_step<32>(m);
   return m;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t m) {
+  m = xor_max_step<1>(m);
+  m = xor_max_step<2>(m);
+  m = xor_max_step<4>(m);
+  m = xor_max_step<8>(m);
+  m = xor_max_step<16>(m);
+  return xor_max_step<32>(m);
 }
 
 template <int DT> __device__ __forceinline__ uint32_t absmax_word(uint32_t m, uint32_t w) {

@@ -138,7 +138,38 @@ constexpr int reg_vecs(int dtype) { return dtype == FPEMU_F32 ? FPEMU_ROWS_REG_V
 constexpr int kBigBlock = 1024;
 constexpr int kBigRegVecs = 16;
 
-template <int FMT, int RM, int DT, int NV, int BLOCK>
+// 16-bit storage: the row maximum of |x| over a lane's four words as PACKED pairs (v_pk_max_*: one instruction per two
+// elements).  keep_nan (torch.max semantics): unsigned maximum of the 15-bit patterns, a NaN pattern is the largest
+// and wins.  Otherwise (block norm never takes a NaN, cpp:791-793): patterns are shifted up by 0x7FFF - INF so that
+// every NaN pattern turns negative as int16 and a SIGNED maximum against the shifted zero ignores it.
+template <int DT> __device__ __forceinline__ uint32_t absmax16_vector(const u32x4 &v, bool keep_nan) {
+  constexpr uint32_t INF = DT == FPEMU_F16 ? 0x7C00u : 0x7F80u;
+  constexpr uint32_t BIAS = 0x7FFFu - INF;
+  uint32_t a[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) a[j] = v[j] & 0x7FFF7FFFu;
+  if (keep_nan) {
+    u16x2 m = __builtin_bit_cast(u16x2, a[0]);
+#pragma unroll
+    for (int j = 1; j < 4; j++) m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, a[j]));
+    const uint32_t w = __builtin_bit_cast(uint32_t, m);
+    const uint32_t lo = w & 0xFFFFu, hi = w >> 16;
+    return lo > hi ? lo : hi;
+  }
+  i16x2 m = i16x2{(int16_t)BIAS, (int16_t)BIAS};
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(i16x2, __builtin_bit_cast(u16x2, a[j]) + splat16(BIAS)));
+  const uint32_t w = __builtin_bit_cast(uint32_t, m);
+  const uint32_t lo = w & 0xFFFFu, hi = w >> 16;  // both >= BIAS, below 0x8000
+  return (lo > hi ? lo : hi) - BIAS;
+}
+
+// R = lane groups (rows) per lane: 2 gives 16-bit storage with short rows a second independent vector in flight per
+// lane (twice the ALU work per byte of fp32 storage; the flat cast holds two for the same reason).  Row j of a lane
+// is in the j-th run of BLOCK >> lg rows of the workgroup's R * (BLOCK >> lg), so a wave's load still covers one
+// contiguous run of rows.
+template <int FMT, int RM, int DT, int NV, int BLOCK, int R = 1>
 __global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *out_, uint64_t rows,
                                                          uint32_t nv, uint32_t lg, float flt_max, int policy,
                                                          uint64_t seed, uint64_t offset, uint32_t *aux) {
@@ -146,72 +177,94 @@ __global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *
   constexpr int kWaves = BLOCK / 64;
   const unsigned G = 1u << lg;
   const unsigned t = threadIdx.x & (G - 1u);
-  const uint64_t row = (((uint64_t)blockIdx.x * BLOCK) >> lg) + (threadIdx.x >> lg);
-  const bool live = row < rows;
-  const u32x4 *vin = reinterpret_cast<const u32x4 *>(in_) + (live ? row : 0) * nv;
-  u32x4 *vout = reinterpret_cast<u32x4 *>(out_) + row * nv;
   const bool bn = (policy == kRowsBlockNorm);
   const bool given = (policy == kRowsGiven);  // uniform over the launch: scalar branches
 
-  u32x4 v[NV];
+  uint64_t row[R];
+  bool live[R];
+  u32x4 v[R][NV];
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const uint32_t i = (uint32_t)k * G + t;
-    v[k] = __builtin_nontemporal_load(&vin[i < nv ? i : 0u]);
-  }
-  float scale;
-  if (given) {
-    scale = u2f(aux[live ? row : 0]);
-  } else {
-    uint32_t m = 0u;
+  for (int q = 0; q < R; q++) {
+    row[q] = ((((uint64_t)blockIdx.x * R + (unsigned)q) * BLOCK) >> lg) + (threadIdx.x >> lg);
+    live[q] = row[q] < rows;
+    const u32x4 *vin = reinterpret_cast<const u32x4 *>(in_) + (live[q] ? row[q] : 0) * nv;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-      const bool ok = live && (uint32_t)k * G + t < nv;
-      uint32_t mk = 0u;
+      const uint32_t i = (uint32_t)k * G + t;
+      v[q][k] = __builtin_nontemporal_load(&vin[i < nv ? i : 0u]);
+    }
+  }
+  float scale[R];
+  if (given) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) mk = absmax_word<DT>(mk, bn ? drop_nan<DT>(v[k][j]) : v[k][j]);
-      mk = ok ? mk : 0u;
-      m = m > mk ? m : mk;
+    for (int q = 0; q < R; q++) scale[q] = u2f(aux[live[q] ? row[q] : 0]);
+  } else {
+    uint32_t m[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      m[q] = 0u;
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        const bool ok = live[q] && (uint32_t)k * G + t < nv;
+        uint32_t mk = 0u;
+        if constexpr (DT == FPEMU_F32) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) mk = absmax_word<DT>(mk, bn ? drop_nan<DT>(v[q][k][j]) : v[q][k][j]);
+        } else {
+          mk = absmax16_vector<DT>(v[q][k], !bn);
+        }
+        mk = ok ? mk : 0u;
+        m[q] = m[q] > mk ? m[q] : mk;
+      }
     }
     // butterfly over the row's lanes (G is uniform: scalar branches)
 #pragma unroll
-    for (unsigned off = 1; off < 64u; off <<= 1) {
-      if (off < G) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)m, (int)off, 64);
-        m = m > o ? m : o;
+    for (int q = 0; q < R; q++) m[q] = group_max_u32(m[q], G < 64u ? G : 64u);
+    if (G == (unsigned)BLOCK) {
+      __shared__ uint32_t part[R][kWaves];
+      if ((threadIdx.x & 63u) == 0u) {
+#pragma unroll
+        for (int q = 0; q < R; q++) part[q][threadIdx.x >> 6] = m[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        uint32_t r = part[q][0];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) r = r > part[q][w] ? r : part[q][w];
+        m[q] = r;
       }
     }
-    uint32_t r = m;
-    if (G == (unsigned)BLOCK) {
-      __shared__ uint32_t part[kWaves];
-      if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = r;
-      __syncthreads();
-      r = part[0];
 #pragma unroll
-      for (int w = 1; w < kWaves; w++) r = r > part[w] ? r : part[w];
+    for (int q = 0; q < R; q++) {
+      uint32_t r = m[q];
+      if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
+      else if constexpr (DT == FPEMU_BF16) r = r << 16;
+      if (aux != nullptr && t == 0u && live[q]) aux[row[q]] = r;
+      scale[q] = bn ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
     }
-    if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
-    else if constexpr (DT == FPEMU_BF16) r = r << 16;
-    if (aux != nullptr && t == 0u && live) aux[row] = r;
-    scale = bn ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
   }
-  const float rcp = scale_reciprocal(scale);
-  const uint64_t roff = offset + row;
 
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const uint32_t i = (uint32_t)k * G + t;
-    const u32x4 o = cast_vector<FMT, RM, DT>(v[k], scale, rcp, ElemNoise<FMT, V>{seed, roff, (uint64_t)i * V});
-    if (live && i < nv) store_stream(&vout[i], o);
+  for (int q = 0; q < R; q++) {
+    const float rcp = scale_reciprocal(scale[q]);
+    const uint64_t roff = offset + row[q];
+    u32x4 *vout = reinterpret_cast<u32x4 *>(out_) + row[q] * nv;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const uint32_t i = (uint32_t)k * G + t;
+      const u32x4 o = cast_vector<FMT, RM, DT>(v[q][k], scale[q], rcp, ElemNoise<FMT, V>{seed, roff, (uint64_t)i * V});
+      if (live[q] && i < nv) store_stream(&vout[i], o);
+    }
   }
 }
 
 typedef void (*rows_reg_fn)(const void *, void *, uint64_t, uint32_t, uint32_t, float, int, uint64_t, uint64_t,
                             uint32_t *);
 
-template <int DT, int NV, int BLOCK = kBlock> rows_reg_fn pick_rows_reg(int fmt, int rm) {
+template <int DT, int NV, int BLOCK = kBlock, int RPL = 1> rows_reg_fn pick_rows_reg(int fmt, int rm) {
 #define FPEMU_CASE(F, R) \
-  if (fmt == F && rm == R) return rows_reg_kernel<F, R, DT, NV, BLOCK>;
+  if (fmt == F && rm == R) return rows_reg_kernel<F, R, DT, NV, BLOCK, RPL>;
   FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
   FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
   FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
@@ -224,7 +277,18 @@ template <int DT, int NV, int BLOCK = kBlock> rows_reg_fn pick_rows_reg(int fmt,
   return nullptr;
 }
 
-template <int DT> rows_reg_fn pick_rows_reg_nv(uint32_t per_lane, int fmt, int rm) {
+#ifndef FPEMU_ROWS_PAIR16
+#define FPEMU_ROWS_PAIR16 1   // tuning: 16-bit storage, one vector per lane, lane group within a wave: two rows per lane
+#endif
+// rocprofv3 kernel durations, bf16 E4M3_RNE block norm over 64 Mi elements (tools/rows_trace.sh), two rows per lane
+// vs one: blocks of 8 (one lane per row) 44.9 vs 42.7 us, 32: 44.3 vs 44.3, 128: 44.9 vs 45.8, 512: 45.0 vs 48.1 --
+// the second vector in flight pays once the row's maximum crosses lanes, so groups of 8 lanes and more take it.
+constexpr int rows_per_lane(int dtype, uint32_t per_lane, uint32_t lg) {
+  return (FPEMU_ROWS_PAIR16 && dtype != FPEMU_F32 && per_lane <= 1 && lg >= 3 && lg <= 6) ? 2 : 1;
+}
+
+template <int DT> rows_reg_fn pick_rows_reg_nv(uint32_t per_lane, uint32_t lg, int fmt, int rm) {
+  if (rows_per_lane(DT, per_lane, lg) == 2) return pick_rows_reg<DT, 1, kBlock, 2>(fmt, rm);
   return per_lane <= 1 ? pick_rows_reg<DT, 1>(fmt, rm)
        : per_lane <= 2 ? pick_rows_reg<DT, 2>(fmt, rm)
        : per_lane <= 4 ? pick_rows_reg<DT, 4>(fmt, rm)
@@ -403,11 +467,11 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
     else if (nv > 64u) lg = 6;
     else while ((1u << lg) < nv) lg++;
     const uint32_t per_lane = (nv + (1u << lg) - 1u) >> lg;
-    rows_reg_fn rf = dtype == FPEMU_F32 ? pick_rows_reg_nv<FPEMU_F32>(per_lane, fmt, rmode)
-                   : dtype == FPEMU_F16 ? pick_rows_reg_nv<FPEMU_F16>(per_lane, fmt, rmode)
-                   : dtype == FPEMU_BF16 ? pick_rows_reg_nv<FPEMU_BF16>(per_lane, fmt, rmode) : nullptr;
+    rows_reg_fn rf = dtype == FPEMU_F32 ? pick_rows_reg_nv<FPEMU_F32>(per_lane, lg, fmt, rmode)
+                   : dtype == FPEMU_F16 ? pick_rows_reg_nv<FPEMU_F16>(per_lane, lg, fmt, rmode)
+                   : dtype == FPEMU_BF16 ? pick_rows_reg_nv<FPEMU_BF16>(per_lane, lg, fmt, rmode) : nullptr;
     if (rf == nullptr) return -100;  // kNoRowsKernel of fpemu_hip.hip
-    const uint64_t per_blk = (uint64_t)kBlock >> lg;
+    const uint64_t per_blk = ((uint64_t)kBlock >> lg) * (unsigned)rows_per_lane(dtype, per_lane, lg);
     const uint64_t nblk = (rows + per_blk - 1) / per_blk;
     if (nblk > 0x7FFFFFFFull) {
       fpemu_set_error_("fpemu rows: more than 2^31-1 workgroups");
