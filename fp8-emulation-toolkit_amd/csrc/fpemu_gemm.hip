@@ -714,14 +714,18 @@ __device__ __forceinline__ void small_coords(int h, int tid, int &r, int &k) {
   }
 }
 
+// whole: (not FULL) this tile lies inside the operand and the operand is vector-aligned -- uniform over the
+// workgroup, so the chain's steady state runs the unchecked load and only a segment's ragged last k tile (the conv
+// weight update: OH*OW = 3136 = 24.5 tiles per image) takes the bounds-checked one.
 template <bool KCONT, bool FULL>
-__device__ __forceinline__ f32x4 small_load_one(const Operand &X, const float *base, int r0, int k0, int tid, int h) {
+__device__ __forceinline__ f32x4 small_load_one(const Operand &X, const float *base, int r0, int k0, int tid, int h,
+                                                bool whole = false) {
   int r, k;
   small_coords<KCONT>(h, tid, r, k);
   r += r0;
   k += k0;
   const float *src = KCONT ? base + (int64_t)r * X.ld + k : base + (int64_t)k * X.ld + r;
-  if constexpr (FULL) return *reinterpret_cast<const f32x4 *>(src);
+  if (FULL || whole) return *reinterpret_cast<const f32x4 *>(src);
   f32x4 t = {0.f, 0.f, 0.f, 0.f};
   const bool in_outer = KCONT ? (r < X.R) : (k < X.K);
   const int inner = KCONT ? k : r, inner_end = KCONT ? X.K : X.R;
@@ -792,6 +796,8 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
       if (row < M && col < N) acc[r] = C[(int64_t)row * ldc + col];
     }
   }
+  // this workgroup's rows / columns are whole tiles of vector-aligned operands: only k can be ragged
+  const bool mn_whole = !FULL && A.vec && B.vec && m0 + SB <= M && n0 + SB <= N;
 
   // A wave's MFMAs form ONE dependent chain (~40 cycles a step), and a wave issues in order: whatever else it
   // has to do -- LDS reads of the next fragments, the next tile's LDS stores, the global loads of the tile after
@@ -868,8 +874,9 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
           const int s16 = q * Q + st;
           if ((s16 & 1) == 0) {
             const int h = s16 >> 2;
-            if (s16 & 2) rb[PAR][h] = small_load_one<B_KCONT, FULL>(B, cur.b, n0, cur.k0, tid, h);
-            else ra[PAR][h] = small_load_one<A_KCONT, FULL>(A, cur.a, m0, cur.k0, tid, h);
+            const bool whole = mn_whole && cur.k0 + SK <= K;
+            if (s16 & 2) rb[PAR][h] = small_load_one<B_KCONT, FULL>(B, cur.b, n0, cur.k0, tid, h, whole);
+            else ra[PAR][h] = small_load_one<A_KCONT, FULL>(A, cur.a, m0, cur.k0, tid, h, whole);
           }
         }
         __builtin_amdgcn_sched_barrier(0);

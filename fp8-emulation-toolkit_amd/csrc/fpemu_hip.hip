@@ -466,6 +466,110 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void *__restrict__ i
 // hipMemsetAsync costs >10 us on this runtime, and the small-tensor regime is host-bound.
 __global__ void zero_word_kernel(uint32_t *w) { *w = 0u; }
 
+// Multi-tensor per-tensor quantisation (fpemu_quantize_per_tensor_multi): launch 1 -- every workgroup reduces its
+// share of ITS tensor to one word of `partials` (indexed by workgroup: no atomics, nothing to zero); launch 2 --
+// the multi-tensor cast, whose workgroups first reduce their tensor's words to the scale (L2 hits, under the HBM
+// latency of their first loads), exactly as the two-launch single-tensor path does.
+struct AmaxTable {
+  const void *in[kMultiTensors];
+  uint64_t n[kMultiTensors];
+  uint64_t nvec[kMultiTensors];       // 16-byte vectors (0: unaligned buffer)
+  uint32_t blk_end[kMultiTensors];    // exclusive prefix end of the tensor's workgroups = of its words in partials
+  uint32_t count;
+};
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void amax_multi_kernel(AmaxTable tab, uint32_t *partials) {
+  constexpr unsigned V = Storage<DT>::V;
+  unsigned t = 0;
+  while (t + 1u < tab.count && blockIdx.x >= tab.blk_end[t]) t++;  // uniform
+  const unsigned first = t == 0u ? 0u : tab.blk_end[t - 1u];
+  const uint64_t tid = (uint64_t)(blockIdx.x - first) * kBlock + threadIdx.x;
+  const uint64_t stride = (uint64_t)(tab.blk_end[t] - first) * kBlock;
+  const u32x4 *in = reinterpret_cast<const u32x4 *>(tab.in[t]);
+  const uint64_t nvec = tab.nvec[t], n = tab.n[t];
+  uint32_t m = 0u;
+#pragma unroll 4
+  for (uint64_t i = tid; i < nvec; i += stride) {
+    const u32x4 v = in[i];  // default cache policy: the cast re-reads these bytes next
+#pragma unroll
+    for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, v[j]);
+  }
+  using elem_t = typename Storage<DT>::elem;
+  const elem_t *ein = reinterpret_cast<const elem_t *>(tab.in[t]);
+  for (uint64_t e = nvec * V + tid; e < n; e += stride) {
+    if constexpr (DT == FPEMU_F32) m = absmax_word<DT>(m, f2u(ein[e]));
+    else m = absmax_word<DT>(m, (uint32_t)ein[e]);
+  }
+  m = wave_max_u32(m);
+  __shared__ uint32_t part[kWavesPerBlock];
+  if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t r = part[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; w++) r = r > part[w] ? r : part[w];
+    if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
+    else if constexpr (DT == FPEMU_BF16) r = r << 16;
+    partials[blockIdx.x] = r;
+  }
+}
+
+template <int kCastBlock>
+struct PartialsScale {  // scale of one tensor of a multi-tensor launch from its workgroup maxima
+  static constexpr int kCastWaves = kCastBlock / 64;
+  const uint32_t *partials;
+  uint32_t npart;
+  float flt_max;
+  int clamp;
+  uint32_t *pub;  // the tensor's amax word; written by the tensor's first workgroup only (nullptr elsewhere)
+  __device__ __forceinline__ void resolve(float &s, float &r) const {
+    __shared__ uint32_t pmax[kCastWaves];
+    uint32_t m = 0u;
+    for (uint32_t i = threadIdx.x; i < npart; i += kCastBlock) {
+      const uint32_t v = partials[i];
+      m = m > v ? m : v;
+    }
+    m = wave_max_u32(m);
+    uint32_t mx = m;
+    if constexpr (kCastWaves > 1) {
+      if ((threadIdx.x & 63u) == 0u) pmax[threadIdx.x >> 6] = m;
+      __syncthreads();
+      mx = pmax[0];
+#pragma unroll
+      for (int w = 1; w < kCastWaves; w++) mx = mx > pmax[w] ? mx : pmax[w];
+    }
+    if (pub != nullptr && threadIdx.x == 0) *pub = mx;
+    s = scale_from_amax(mx, flt_max, clamp != 0);
+    r = scale_reciprocal(s);
+  }
+};
+
+struct MultiScaleArgs {
+  uint32_t pend[kMultiTensors];  // exclusive prefix end of the tensor's words in partials
+  const uint32_t *partials;
+  uint32_t *amax_words;          // one per tensor of this launch
+  float flt_max;
+  int clamp;
+};
+
+template <int FMT, int RM, int DT>
+__global__ __launch_bounds__(cast_block(RM, DT)) void cast_multi_scaled_kernel(MultiTable tab, MultiScaleArgs ms,
+                                                                               uint64_t seed, uint64_t offset) {
+  unsigned t = 0;
+  while (t + 1u < tab.count && blockIdx.x >= tab.blk_end[t]) t++;  // uniform
+  const unsigned first = t == 0u ? 0u : tab.blk_end[t - 1u];
+  const unsigned pfirst = t == 0u ? 0u : ms.pend[t - 1u];
+  const PartialsScale<cast_block(RM, DT)> src{ms.partials + pfirst, ms.pend[t] - pfirst, ms.flt_max, ms.clamp,
+                                              blockIdx.x == first ? ms.amax_words + t : nullptr};
+  if constexpr (sr_by_slot(RM, DT))
+    cast_blocks_sr<FMT, RM, DT>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], src, seed, offset + t, 0, blockIdx.x - first,
+                                tab.blk_end[t] - first);
+  else
+    cast_blocks<FMT, RM, DT, cast_block(RM, DT)>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], src, seed, offset + t, 0,
+                                                 blockIdx.x - first, tab.blk_end[t] - first);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host side: dispatch tables and launch geometry.
 // ---------------------------------------------------------------------------------------------
@@ -510,6 +614,23 @@ template <int DT> cast_multi_fn pick_cast_multi(int fmt, int rm) {
   FPEMU_CASE(FP4, RNE)
 #undef FPEMU_CASE
   return nullptr;
+}
+
+typedef void (*cast_multi_scaled_fn)(MultiTable, MultiScaleArgs, uint64_t, uint64_t);
+
+template <int DT> cast_multi_scaled_fn pick_cast_multi_scaled(int fmt, int rm) {
+#define FPEMU_CASE(F, R) \
+  if (fmt == F && rm == R) return cast_multi_scaled_kernel<F, R, DT>;
+  FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
+  FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
+  FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
+  FPEMU_CASE(E5M2_DAZ, RNTZ)
+  FPEMU_CASE(E4M3, RTZ) FPEMU_CASE(E4M3, RNE) FPEMU_CASE(E4M3, STOCHASTIC)
+  FPEMU_CASE(E3M4, RTZ) FPEMU_CASE(E3M4, RNE) FPEMU_CASE(E3M4, STOCHASTIC)
+  FPEMU_CASE(E4M3_IEEE, RNE) FPEMU_CASE(E4M3_IEEE, STOCHASTIC)
+  FPEMU_CASE(FP4, RNE)
+#undef FPEMU_CASE
+  return nullptr;  // BF16 / FP16 take no scale
 }
 
 cast_fn pick_cast_dt(int dtype, int fmt, int rm, bool wide = false) {
@@ -715,6 +836,100 @@ int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, i
       hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kCastBlock), 0, (hipStream_t)stream, tab, scale, rcp, seed,
                          offset + first);
       hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+  }
+  return FPEMU_OK;
+}
+
+int fpemu_quantize_per_tensor_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, int fmt, int rmode,
+                                    float flt_max, int clamp, uint32_t *ws, uint64_t ws_words, uint64_t seed,
+                                    uint64_t offset, void *stream) {
+  const char *who = "fpemu_quantize_per_tensor_multi";
+  char msg[128];
+  auto bad = [&](int code, const char *what) {
+    snprintf(msg, sizeof(msg), "%s: %s", who, what);
+    return fail(code, msg);
+  };
+  if (count == 0) return FPEMU_OK;
+  if (tensors == nullptr) return bad(FPEMU_EINVAL, "null tensor table");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return bad(FPEMU_EINVAL, "bad dtype id");
+  const cast_multi_scaled_fn fn = dtype == FPEMU_F32   ? pick_cast_multi_scaled<FPEMU_F32>(fmt, rmode)
+                                  : dtype == FPEMU_F16 ? pick_cast_multi_scaled<FPEMU_F16>(fmt, rmode)
+                                                       : pick_cast_multi_scaled<FPEMU_BF16>(fmt, rmode);
+  if (fn == nullptr) return bad(FPEMU_EINVAL, "format / rounding-mode pair takes no scale or is not defined");
+  const uint64_t per_launch = count < (uint64_t)kMultiTensors ? count : (uint64_t)kMultiTensors;
+  if (ws == nullptr || ws_words < count + per_launch) return bad(FPEMU_EINVAL, "workspace smaller than count + min(count, 32) words");
+  uint64_t pcap = (ws_words - count) / per_launch;  // words of partials per tensor
+  if (pcap > kMaxPartials) pcap = kMaxPartials;
+  const unsigned es = elem_size(dtype), ve = vec_elems(dtype);
+  for (uint64_t i = 0; i < count; i++) {  // validate everything before the first launch
+    if (tensors[i].n != 0 && (tensors[i].in == nullptr || tensors[i].out == nullptr)) return bad(FPEMU_EINVAL, "null buffer");
+    if (((uintptr_t)tensors[i].in % es) || ((uintptr_t)tensors[i].out % es))
+      return bad(FPEMU_EALIGN, "buffer not aligned to its element size");
+  }
+  typedef void (*amax_multi_fn)(AmaxTable, uint32_t *);
+  const amax_multi_fn afn = dtype == FPEMU_F32   ? (amax_multi_fn)amax_multi_kernel<FPEMU_F32>
+                            : dtype == FPEMU_F16 ? (amax_multi_fn)amax_multi_kernel<FPEMU_F16>
+                                                 : (amax_multi_fn)amax_multi_kernel<FPEMU_BF16>;
+  const uint64_t sb_elems = (uint64_t)ve * 64u * (unsigned)slots_per_wave(rmode, dtype);
+  const unsigned kCastBlock = (unsigned)cast_block(rmode, dtype);
+  uint32_t *partials = ws + count;
+  uint64_t i = 0;
+  while (i < count) {
+    MultiTable tab;
+    AmaxTable at;
+    MultiScaleArgs ms;
+    memset(&tab, 0, sizeof(tab));
+    memset(&at, 0, sizeof(at));
+    memset(&ms, 0, sizeof(ms));
+    uint64_t blocks = 0, ablocks = 0;
+    unsigned k = 0;
+    const uint64_t first = i;
+    for (; i < count && k < (unsigned)kMultiTensors; i++, k++) {
+      const fpemu_tensor_t &t = tensors[i];
+      const bool vec_ok = (((uintptr_t)t.in | (uintptr_t)t.out) % 16u) == 0;
+      const uint64_t nsb = vec_ok ? t.n / sb_elems : 0;
+      const uint64_t tail = t.n - nsb * sb_elems;
+      uint64_t b = superblock_groups(nsb, rmode, dtype);
+      const uint64_t tb = (tail + kCastBlock - 1) / kCastBlock;
+      if (b < tb) b = tb;
+      if (b > (uint64_t)max_blocks()) b = (uint64_t)max_blocks();
+      if (blocks + b > 0x7FFFFFFFull) {
+        if (k == 0) return bad(FPEMU_EINVAL, "tensor too large for one launch; use fpemu_quantize_per_tensor_ws");
+        break;  // this tensor starts the next launch
+      }
+      blocks += b;  // an empty tensor owns no workgroups (and still consumes its offset)
+      tab.in[k] = t.in;
+      tab.out[k] = t.out;
+      tab.n[k] = t.n;
+      tab.nsb[k] = nsb;
+      tab.blk_end[k] = (uint32_t)blocks;
+      // amax workgroups: at least four vectors (or 16 elements) per thread, at most pcap words
+      const bool avec = ((uintptr_t)t.in % 16u) == 0;
+      const uint64_t nvec = avec ? t.n / ve : 0;
+      uint64_t ab = avec ? nvec / (4u * kBlock) : t.n / (16u * kBlock);
+      if (ab > pcap) ab = pcap;
+      if (ab < 1 && t.n != 0) ab = 1;
+      ablocks += ab;
+      at.in[k] = t.in;
+      at.n[k] = t.n;
+      at.nvec[k] = nvec;
+      at.blk_end[k] = (uint32_t)ablocks;
+      ms.pend[k] = (uint32_t)ablocks;
+    }
+    tab.count = k;
+    at.count = k;
+    if (blocks != 0) {
+      hipLaunchKernelGGL(afn, dim3((unsigned)ablocks), dim3(kBlock), 0, (hipStream_t)stream, at, partials);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+      ms.partials = partials;
+      ms.amax_words = ws + first;
+      ms.flt_max = flt_max;
+      ms.clamp = clamp ? 1 : 0;
+      hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kCastBlock), 0, (hipStream_t)stream, tab, ms, seed, offset + first);
+      e = hipGetLastError();
       if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     }
   }

@@ -87,7 +87,9 @@ def lib():
         L.fpemu_quantize_blocks.argtypes = [vp, vp, u64, u64, i32, i32, i32, u64, u64, vp]
         L.fpemu_cast_multi.restype = i32
         L.fpemu_cast_multi.argtypes = [vp, u64, i32, i32, i32, f32, u64, u64, vp]
-        if L.fpemu_abi_version() != 7:
+        L.fpemu_quantize_per_tensor_multi.restype = i32
+        L.fpemu_quantize_per_tensor_multi.argtypes = [vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, u64, vp]
+        if L.fpemu_abi_version() != 8:
             raise ImportError("libfpemu_hip.so: ABI version mismatch")
         _lib = L
     return _lib
@@ -294,6 +296,40 @@ def cast_multi_(srcs, fmt, rmode, scale=1.0, dsts=None, seed=None, offset=None):
         _check(lib().fpemu_cast_multi(ctypes.cast(tab, ctypes.c_void_p), len(srcs), _dtype_id(first), fmt, rmode,
                                       float(scale), _seed if seed is None else seed, offset, _stream(first)))
     return dsts
+
+
+def quantize_per_tensor_multi_(srcs, fmt, rmode, flt_max, dsts=None, clamp=True, ws=None):
+    """Per-tensor amax -> device-side scale -> cast of a list of contiguous tensors of one dtype on one device (in
+    place unless `dsts` is given), two launches per 32 tensors.  Tensor i is quantised exactly as
+    quantize_per_tensor_() would at call offset `offset + i`; the call counter advances by len(srcs).
+    ws: int32 scratch of at least len(srcs) + min(len(srcs), 32) words (default: len + 32 * 256, allocated here);
+    afterwards ws[i] holds tensor i's amax bit pattern.  Returns (dsts, ws)."""
+    srcs = list(srcs)
+    dsts = srcs if dsts is None else list(dsts)
+    if len(dsts) != len(srcs):
+        raise ValueError("fpemu: input/output lists differ in length")
+    if not srcs:
+        return dsts, ws
+    first = srcs[0]
+    tab = (_TensorEntry * len(srcs))()
+    for i, (a, b) in enumerate(zip(srcs, dsts)):
+        _require_device(a)
+        _require_device(b, "output")
+        if a.dtype != first.dtype or a.device != first.device or b.dtype != a.dtype or b.device != a.device:
+            raise ValueError("fpemu: quantize_per_tensor_multi_ needs tensors of one dtype on one device")
+        if b.numel() != a.numel():
+            raise ValueError("fpemu: input/output mismatch")
+        tab[i].inp, tab[i].out, tab[i].n = a.data_ptr(), b.data_ptr(), a.numel()
+    if ws is None:
+        ws = torch.empty(len(srcs) + 32 * 256, dtype=torch.int32, device=first.device)
+    elif ws.dtype != torch.int32 or ws.device != first.device or not ws.is_contiguous():
+        raise ValueError("fpemu: workspace must be a contiguous int32 tensor on the tensors' device")
+    offset = _take_offsets(len(srcs)) if rmode == STOCHASTIC else 0
+    with _range("fpemu::quantize_per_tensor_multi"), _on_device(first):
+        _check(lib().fpemu_quantize_per_tensor_multi(ctypes.cast(tab, ctypes.c_void_p), len(srcs), _dtype_id(first), fmt,
+                                                     rmode, float(flt_max), int(bool(clamp)), ws.data_ptr(), ws.numel(),
+                                                     _seed, offset, _stream(first)))
+    return dsts, ws
 
 
 def amax_(src, amax_bits):

@@ -495,10 +495,31 @@ def quantize_weights_of_a_module(module, wt_qconfig, name=""):
 
 
 def quantize_model_weights(model, model_qconfig_dict):
+    """The reference's loop of quantize_weights_of_a_module over the model (qutils.py:470-475).  Weights whose
+    configuration is per-tensor "max" scaling with a deterministic rounding mode -- what every emulator preset
+    gives Linear / Conv2d weights outside the per-channel presets -- are collected per (configuration, dtype,
+    device) and quantised in place by fpemu_quantize_per_tensor_multi: two launches per 32 weights instead of one to
+    three per weight, bit for bit the loop's result (tensor i of a call is quantised exactly as the single-tensor
+    call would; deterministic modes consume no call offsets, so the order of the calls does not matter).
+    Everything else takes the loop."""
+    batches = OrderedDict()
     for name, module in model.named_modules():
         cfg = model_qconfig_dict.get(name)
-        if cfg is not None and cfg.wt_qconfig is not None:
-            quantize_weights_of_a_module(module, cfg.wt_qconfig, name=name)
+        if cfg is None or cfg.wt_qconfig is None:
+            continue
+        qt = cfg.wt_qconfig
+        w = module.weight.data
+        plan = getattr(qt, "_plan", None) or _plan(qt)
+        if (plan[0] == 1 and plan[3] != _hip.STOCHASTIC and w.is_cuda and w.is_contiguous() and not w.is_sparse
+                and _amax_group is None and w.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+            batches.setdefault((plan[2], plan[3], plan[4], w.dtype, w.device), []).append(w)
+        else:
+            quantize_weights_of_a_module(module, qt, name=name)
+    for (fmt, rmode, flt_max, _, _), weights in batches.items():
+        if len(weights) == 1:
+            _hip.quantize_per_tensor_(weights[0], weights[0], fmt, rmode, flt_max)
+        else:
+            _hip.quantize_per_tensor_multi_(weights, fmt, rmode, flt_max)
 
 
 def _active(qtconfig):

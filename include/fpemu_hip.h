@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FPEMU_ABI_VERSION 7
+#define FPEMU_ABI_VERSION 8
 
 /* Storage dtype of in/out buffers. */
 enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
@@ -108,6 +108,20 @@ typedef struct fpemu_tensor {
 } fpemu_tensor_t;
 int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, int fmt, int rmode, float scale,
                      uint64_t seed, uint64_t offset, void *stream);
+
+/* fpemu_quantize_per_tensor for a LIST of buffers of one storage type and mode in two launches per 32 tensors
+ * (per-workgroup maxima of every tensor; then the multi-tensor cast, whose workgroups reduce their tensor's
+ * maxima to its scale) instead of one to three launches per tensor.  For the callers that quantise many weights
+ * in a row with one configuration: quantize_model_weights (reference qutils.py:478-487, a Python loop of
+ * quantize_tensor over the model's modules) and the emulators' weight hooks.  Tensor i is quantised exactly as
+ * fpemu_quantize_per_tensor(in_i, out_i, n_i, ..., seed, offset + i): the same bits as the loop it replaces.
+ *   ws : count + 32 * 256 words for the full effect (at least count + min(count, 32)), contents need not be
+ *        initialised; in stream order after the call ws[i] holds tensor i's amax bit pattern (empty tensors:
+ *        not written).  One workspace per stream.
+ * Formats without a scale (BF16 / FP16) are rejected: they are fpemu_cast_multi. */
+int fpemu_quantize_per_tensor_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, int fmt, int rmode,
+                                    float flt_max, int clamp, uint32_t *ws, uint64_t ws_words, uint64_t seed,
+                                    uint64_t offset, void *stream);
 
 /* Mirror of the pybind `forward` signature (hip/fpemu_impl.cpp:27-37): mode string, size,
  * scale, block_norm, block_size.  inplace <=> out == in.  block_norm: as the reference

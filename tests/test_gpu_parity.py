@@ -550,3 +550,56 @@ def test_cast_multi_rejects_mixed_lists(hip):
         hip.cast_multi_([a], *hip.parse_mode("E4M3_RNE"), dsts=[torch.empty(9, device=DEV)])
     with pytest.raises(RuntimeError):
         hip.cast_multi_([a, torch.randn(8)], *hip.parse_mode("E4M3_RNE"))
+
+
+@pytest.mark.parametrize("mode", ["E4M3_RNE", "E5M2_STOCHASTIC", "E3M4_RNE"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_quantize_per_tensor_multi_equals_the_loop(hip, mode, dt):
+    """fpemu_quantize_per_tensor_multi: tensor i == fpemu_quantize_per_tensor at call offset + i (bits, amax words,
+    offsets consumed), over ragged sizes, an empty tensor, unaligned views, more than 32 tensors (two launch
+    groups), tensors on either side of the one-workgroup size, and a workspace at its minimum size."""
+    fmt, rm = hip.parse_mode(mode)
+    fmax = FLT_MAX[mode.split("_")[0]]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    sizes = [1, 7, 0, 1000, 4097, 32768, 32769, 70001, 1 << 20, (1 << 21) + 5] + [257 * (i + 1) for i in range(30)]
+    srcs = []
+    for i, n in enumerate(sizes):
+        base = (torch.randn(n + 3, device=DEV, generator=g) * (0.01 + 3 * i)).to(dt)
+        srcs.append(base[1:1 + n] if i % 4 == 1 else base[:n])       # every fourth: not 16-byte aligned
+    srcs[5][17] = 1e4
+    want, words = [], []
+    hip.set_rng_state((21, 300))
+    for t in srcs:
+        o = torch.empty_like(t)
+        ws1 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        hip.quantize_per_tensor_(t, o, fmt, rm, fmax, amax_ws=ws1)
+        want.append(o)
+        words.append(int(ws1.item()))
+    used = hip.get_rng_state()
+    for ws_words in (None, len(srcs) + 32):
+        hip.set_rng_state((21, 300))
+        dsts = [torch.empty_like(t) for t in srcs]
+        ws = None if ws_words is None else torch.empty(ws_words, dtype=torch.int32, device=DEV)
+        _, ws = hip.quantize_per_tensor_multi_(srcs, fmt, rm, fmax, dsts=dsts, ws=ws)
+        assert hip.get_rng_state() == used
+        for i, (a, b) in enumerate(zip(dsts, want)):
+            v = torch.int32 if dt == torch.float32 else torch.int16
+            assert torch.equal(a.view(v), b.view(v)), (mode, dt, i, sizes[i], ws_words)
+            if sizes[i]:
+                assert int(ws[i].item()) == words[i], (i, sizes[i])
+    # in place
+    hip.set_rng_state((21, 300))
+    clones = [t.clone() for t in srcs]
+    hip.quantize_per_tensor_multi_(clones, fmt, rm, fmax)
+    for a, b in zip(clones, want):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_quantize_per_tensor_multi_argument_errors(hip):
+    t = [torch.randn(100, device=DEV) for _ in range(3)]
+    with pytest.raises(ValueError):  # BF16 takes no scale
+        hip.quantize_per_tensor_multi_(t, *hip.parse_mode("BFLOAT16_RNE"), 1.0)
+    with pytest.raises(ValueError):  # workspace too small
+        hip.quantize_per_tensor_multi_(t, *hip.parse_mode("E4M3_RNE"), 448.0, ws=torch.empty(5, dtype=torch.int32, device=DEV))
+    with pytest.raises(ValueError):  # mixed dtypes
+        hip.quantize_per_tensor_multi_([t[0], t[1].half()], *hip.parse_mode("E4M3_RNE"), 448.0)
