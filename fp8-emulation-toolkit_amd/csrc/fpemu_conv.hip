@@ -46,10 +46,11 @@ struct Geo {
 __device__ __forceinline__ int64_t gtid() { return (int64_t)blockIdx.x * NT + threadIdx.x; }
 __device__ __forceinline__ int64_t gstride() { return (int64_t)gridDim.x * NT; }
 
-// Wfp[k][(cb, kj, ki, c2)] = w[k][cb*CB + c2][kj][ki]
-__global__ __launch_bounds__(NT) void pack_w_fp(const float *__restrict__ w, float *__restrict__ Wm, Geo g) {
+// Wfp[k][(cb, kj, ki, c2)] = w[k][cb*CB + c2][kj][ki]      (first / step: this thread's share of a launch)
+__device__ __forceinline__ void pack_w_fp_body(const float *__restrict__ w, float *__restrict__ Wm, const Geo &g,
+                                               int64_t first, int64_t step) {
   const int64_t crs = g.C * g.R * g.S, total = g.K * crs;
-  for (int64_t i = gtid(); i < total; i += gstride()) {
+  for (int64_t i = first; i < total; i += step) {
     const int64_t k = i / crs;
     int64_t kk = i % crs;
     const int64_t c2 = kk % g.CB; kk /= g.CB;
@@ -58,6 +59,9 @@ __global__ __launch_bounds__(NT) void pack_w_fp(const float *__restrict__ w, flo
     const int64_t cb = kk / g.R;
     Wm[i] = w[((k * g.C + cb * g.CB + c2) * g.R + kj) * g.S + ki];
   }
+}
+__global__ __launch_bounds__(NT) void pack_w_fp(const float *__restrict__ w, float *__restrict__ Wm, Geo g) {
+  pack_w_fp_body(w, Wm, g, gtid(), gstride());
 }
 
 // gw[k][c][kj][ki] = Gw[k][(cb, kj, ki, c2)]
@@ -75,9 +79,10 @@ __global__ __launch_bounds__(NT) void unpack_gw(const float *__restrict__ Gm, fl
 }
 
 // Wbp[c][(ob, tj, ti, o2)] = w[ob*KB + o2][c][R-1-tj][ti]      (oj ascending = kj descending)
-__global__ __launch_bounds__(NT) void pack_w_bp(const float *__restrict__ w, float *__restrict__ Wm, Geo g) {
+__device__ __forceinline__ void pack_w_bp_body(const float *__restrict__ w, float *__restrict__ Wm, const Geo &g,
+                                               int64_t first, int64_t step) {
   const int64_t krs = g.K * g.R * g.S, total = g.C * krs;
-  for (int64_t i = gtid(); i < total; i += gstride()) {
+  for (int64_t i = first; i < total; i += step) {
     const int64_t c = i / krs;
     int64_t kk = i % krs;
     const int64_t o2 = kk % g.KB; kk /= g.KB;
@@ -86,6 +91,9 @@ __global__ __launch_bounds__(NT) void pack_w_bp(const float *__restrict__ w, flo
     const int64_t ob = kk / g.R;
     Wm[i] = w[(((ob * g.KB + o2) * g.C + c) * g.R + (g.R - 1 - tj)) * g.S + ti];
   }
+}
+__global__ __launch_bounds__(NT) void pack_w_bp(const float *__restrict__ w, float *__restrict__ Wm, Geo g) {
+  pack_w_bp_body(w, Wm, g, gtid(), gstride());
 }
 
 // cols[n][(cb, kj, ki, c2)][(oj, oi)] = x[n0 + n][cb*CB + c2][oj*s + kj - pad][oi*s + ki - pad], 0 outside.
@@ -184,10 +192,27 @@ __global__ __launch_bounds__(NT) void cols_bp(const float *__restrict__ go, floa
 // of every plane, zero-pad the planes ONCE; the chain GEMM then reads row (c, kj, ki) of its operand as plane c
 // shifted by kj*Wp + ki (fpemu_gemm.hip, ConvMap).  xp[n][c][y][x] = x[n][c][y - ph][x - pw], 0 outside.
 // Four consecutive elements per thread, one 16-byte store.
+// PACK 1 / 2: workgroups past the first pad_blocks pack the weights (pack_w_fp / pack_w_bp) in the same launch -- the
+// GEMM that follows needs both, and a launch boundary costs these 100 us convolutions ~5 %.
+struct PackJob {
+  const float *w;
+  float *Wm;
+  Geo g;
+};
+template <int PACK>
 __global__ __launch_bounds__(NT) void pad_planes(const float *__restrict__ x, float *__restrict__ xp, int64_t planes,
-                                                 int H, int W, int Hp, int Wp, int ph, int pw) {
+                                                 int H, int W, int Hp, int Wp, int ph, int pw, unsigned pad_blocks,
+                                                 PackJob job) {
+  if constexpr (PACK != 0) {
+    if (blockIdx.x >= pad_blocks) {  // uniform
+      const int64_t first = (int64_t)(blockIdx.x - pad_blocks) * NT + threadIdx.x, step = (int64_t)(gridDim.x - pad_blocks) * NT;
+      if constexpr (PACK == 1) pack_w_fp_body(job.w, job.Wm, job.g, first, step);
+      else pack_w_bp_body(job.w, job.Wm, job.g, first, step);
+      return;
+    }
+  }
   const int64_t plane = (int64_t)Hp * Wp, total = planes * plane;
-  for (int64_t i = gtid() * 4; i < total; i += gstride() * 4) {
+  for (int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 4; i < total; i += (int64_t)pad_blocks * NT * 4) {
     f32x4 o;
     int64_t pl = i / plane;
     int rem = (int)(i - pl * plane);
@@ -400,10 +425,19 @@ namespace {
 // Returns FPEMU_OK, an error, or 1 when the workspace cannot hold even one image (caller falls back).
 int implicit_conv(const char *who, float *out, const float *src, const float *Wm, const float *bias, int64_t N,
                   int64_t chans, int64_t Hs, int64_t Ws, int64_t M, int64_t R, int64_t S, int64_t ph, int64_t pw,
-                  int64_t OH, int64_t OW, int reverse, float *xp, int64_t xp_floats, hipStream_t s) {
+                  int64_t OH, int64_t OW, int reverse, float *xp, int64_t xp_floats, hipStream_t s, int pack,
+                  const PackJob &job) {
+  // pack: 1 / 2 = the weights are not packed yet (forward / backward-data layout); done in the first launch here
   const int64_t Hp = Hs + 2 * ph, Wp = Ws + 2 * pw;
+  const int64_t wtotal = pack == 1 ? job.g.K * job.g.C * job.g.R * job.g.S : pack == 2 ? job.g.C * job.g.K * job.g.R * job.g.S : 0;
+  auto pack_alone = [&]() {
+    if (pack == 1) hipLaunchKernelGGL(pack_w_fp, dim3(blocks_for(wtotal)), dim3(NT), 0, s, job.w, job.Wm, job.g);
+    else if (pack == 2) hipLaunchKernelGGL(pack_w_bp, dim3(blocks_for(wtotal)), dim3(NT), 0, s, job.w, job.Wm, job.g);
+  };
   // no padding (1 x 1 filters, ...) and whole tiles: the source planes ARE the operand, nothing is read past them
   if (ph == 0 && pw == 0 && R == 1 && S == 1 && N <= 65535 && (OH * Wp) % fpemu_gemm_conv_tile_(M, OH * Wp, N) == 0) {
+    pack_alone();
+    CHECK_LAUNCH(who);
     const int rc = fpemu_gemm_conv_launch_(out, Wm, src, bias, N, M, chans / 64, R, S, Hp * Wp, Wp, OH, OW, reverse, (void *)s);
     if (rc != 0) return fail(who, rc, hipGetErrorString((hipError_t)rc));
     return FPEMU_OK;
@@ -414,8 +448,11 @@ int implicit_conv(const char *who, float *out, const float *src, const float *Wm
   if (chunk > 65535) chunk = 65535;
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL(pad_planes, dim3(blocks_for((nb * chans * Hp * Wp + 3) / 4)), dim3(NT), 0, s,
-                       src + n0 * chans * Hs * Ws, xp, nb * chans, (int)Hs, (int)Ws, (int)Hp, (int)Wp, (int)ph, (int)pw);
+    const unsigned pb = blocks_for((nb * chans * Hp * Wp + 3) / 4);
+    const unsigned wb = (n0 == 0 && pack != 0) ? blocks_for(wtotal) : 0u;  // the weights ride on the first chunk's launch
+    hipLaunchKernelGGL(wb == 0 ? pad_planes<0> : pack == 1 ? pad_planes<1> : pad_planes<2>, dim3(pb + wb), dim3(NT), 0, s,
+                       src + n0 * chans * Hs * Ws, xp, nb * chans, (int)Hs, (int)Ws, (int)Hp, (int)Wp, (int)ph, (int)pw, pb,
+                       job);
     CHECK_LAUNCH(who);
     const int rc = fpemu_gemm_conv_launch_(out + n0 * M * OH * OW, Wm, xp, bias, nb, M, chans / 64, R, S, Hp * Wp, Wp,
                                            OH, OW, reverse, (void *)s);
@@ -463,14 +500,14 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   hipStream_t s = (hipStream_t)stream;
   float *Wm = (float *)ws, *cols = Wm + wf;
   const int64_t P = g.OH * g.OW, crs = C * R * S;
-  hipLaunchKernelGGL(pack_w_fp, dim3(blocks_for(K * crs)), dim3(NT), 0, s, w, Wm, g);
-  CHECK_LAUNCH(who);
   if (FPEMU_CONV_IMPLICIT && variant == 1 && stride == 1 && C % 64 == 0 && K % 64 == 0) {
     rc = implicit_conv(who, out, in, Wm, bias, N, C, H, W, K, R, S, pad, pad, g.OH, g.OW, 0, cols,
-                       (int64_t)(ws_bytes / 4) - wf, s);
-    if (rc != 1) return rc;  // 1: workspace too small for the padded planes -> the gathered form below
+                       (int64_t)(ws_bytes / 4) - wf, s, 1, PackJob{w, Wm, g});
+    if (rc != 1) return rc;  // 1: workspace too small for the padded planes (nothing launched) -> the gathered form below
   }
   if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
+  hipLaunchKernelGGL(pack_w_fp, dim3(blocks_for(K * crs)), dim3(NT), 0, s, w, Wm, g);
+  CHECK_LAUNCH(who);
   hipLaunchKernelGGL(fill_rows, dim3(blocks_for(N * K * P)), dim3(NT), 0, s, out, bias, K, P, N * K * P,
                      (int)(C % 64 != 0));
   CHECK_LAUNCH(who);
@@ -515,17 +552,17 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
     CHECK_LAUNCH(who);
     return FPEMU_OK;
   }
-  hipLaunchKernelGGL(pack_w_bp, dim3(blocks_for(C * krs)), dim3(NT), 0, s, w, Wm, g);
-  CHECK_LAUNCH(who);
   // stride 1: backward-data is the correlation of gout, zero-padded by R-1-pad / S-1-pad, with the packed
   // (flipped) weights: (ob, tj, ti, o2) ascending = the reference's (ob, oj, ki, o2) order
   if (FPEMU_CONV_IMPLICIT && variant == 1 && stride == 1 && C % 64 == 0 && K % 64 == 0 && R - 1 - pad >= 0 &&
       S - 1 - pad >= 0) {
     rc = implicit_conv(who, gin, gout, Wm, nullptr, N, K, g.OH, g.OW, C, R, S, R - 1 - pad, S - 1 - pad, H, W, 1, cols,
-                       (int64_t)(ws_bytes / 4) - wf, s);
+                       (int64_t)(ws_bytes / 4) - wf, s, 2, PackJob{w, Wm, g});
     if (rc != 1) return rc;
   }
   if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
+  hipLaunchKernelGGL(pack_w_bp, dim3(blocks_for(C * krs)), dim3(NT), 0, s, w, Wm, g);
+  CHECK_LAUNCH(who);
   hipLaunchKernelGGL(fill_rows, dim3(blocks_for(N * C * HW)), dim3(NT), 0, s, gin, (const float *)nullptr, C, HW,
                      N * C * HW, 0);
   CHECK_LAUNCH(who);
