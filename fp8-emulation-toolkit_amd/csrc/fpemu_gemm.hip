@@ -684,11 +684,31 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc, float alpha, 
 
 // The implicit convolution's form: A = packed weights [M][segments * 64] (k contiguous), B = padded image planes
 // ([64 channels][plane], positions contiguous), whole tiles only.
+#ifdef FPEMU_GEMM_TRACE  // tuning builds (tools/conv_trace.py): per-workgroup start / end time (100 MHz) and hardware id
+__device__ unsigned long long *g_conv_trace = nullptr;
+#endif
 template <int TW>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FPEMU_GEMM_WAVES)))
 void gemm_mfma_conv_kernel(Operand A, Operand B, float *C, int tiles_m, int tiles_n, Batch bt, ConvMap cm) {
+#ifdef FPEMU_GEMM_TRACE
+  const unsigned long long t0 = wall_clock64();
+#endif
   gemm_mfma_body<true, false, true, true, TW, true>(A, B, C, 0, 1.0f, 0.0f, tiles_m, tiles_n, bt, cm);
+#ifdef FPEMU_GEMM_TRACE
+  if (threadIdx.x == 0 && g_conv_trace != nullptr) {
+    const unsigned long long idx = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    g_conv_trace[3 * idx] = t0;
+    g_conv_trace[3 * idx + 1] = wall_clock64();
+    g_conv_trace[3 * idx + 2] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
+#ifdef FPEMU_GEMM_TRACE
+extern "C" int fpemu_test_conv_trace_(void *ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_trace), &ptr, sizeof(ptr));
+}
+#endif
 
 typedef void (*mfma_fn_t)(Operand, Operand, float *, int64_t, float, float, int, int, Batch);
 
