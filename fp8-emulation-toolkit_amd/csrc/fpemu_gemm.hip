@@ -721,7 +721,16 @@ typedef void (*mfma_fn_t)(Operand, Operand, float *, int64_t, float, float, int,
 // one 16x16 accumulator tile per wave; 128-deep k tiles (32 dependent steps per barrier).
 // Lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; D[reg]: row = 4*(l>>4) + reg, col = l&15.
 // ---------------------------------------------------------------------------------------------
-constexpr int SB = 32, SK = 128, SLD = SB + 4, SNV = SK * SB / (4 * NT);
+// LDS layout of a [SK][SB] tile: element (k, col) at k * SLD + (col ^ swz(k)), SLD = 48, swz(k) = 4 * ((k >> 2) & 7).
+// Bank = address mod 32.  Fragment read of step s (lanes li < 16, lk < 4: k = 4s + lk, col = w + li): k * 48 = lk * 16
+// (mod 32) and the XOR, the same for every lane of the instruction, permutes an aligned block of 16 columns -- the 32
+// lanes of each half-wave hit 32 banks.  Transposing store of a k-contiguous operand (lanes: 4 rows x 8 groups of four
+// k per half-wave; one of the four k per instruction): k * 48 = 16c (mod 32) for every group, and the XOR spreads the
+// groups over the eight aligned blocks of four columns -- 32 banks again.  (With the padded layout SLD = SB + 4 these
+// stores were 4-way and the reads 2-way conflicts, and the LDS pipe -- 1024 + 512 cycles per 1024-cycle tile --
+// was what the chain waited for.)
+constexpr int SB = 32, SK = 128, SLD = 48, SNV = SK * SB / (4 * NT);
+__device__ __forceinline__ int small_swz(int k) { return ((k >> 2) & 7) << 2; }
 
 template <bool KCONT>
 __device__ __forceinline__ void small_coords(int h, int tid, int &r, int &k) {
@@ -761,15 +770,33 @@ __device__ __forceinline__ f32x4 small_load_one(const Operand &X, const float *b
   return t;
 }
 
+// Vector-aligned operands (X.vec: base, strides and the contiguous extent are multiples of four elements, so a
+// thread's four elements are inside the operand together or outside together): ONE unconditional 16-byte load from
+// the element's address, or from the tile base when it lies outside, and a select -- no branch, so the compiler can
+// count the loads in flight.
+template <bool KCONT>
+__device__ __forceinline__ f32x4 small_load_masked(const Operand &X, const float *base, int r0, int k0, int tid, int h) {
+  int r, k;
+  small_coords<KCONT>(h, tid, r, k);
+  r += r0;
+  k += k0;
+  const bool in = r < X.R && k < X.K;
+  const float *src = in ? (KCONT ? base + (int64_t)r * X.ld + k : base + (int64_t)k * X.ld + r) : base;
+  const f32x4 t = *reinterpret_cast<const f32x4 *>(src);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return in ? t : z;
+}
+
 template <bool KCONT>
 __device__ __forceinline__ void small_store_one(float *T, int tid, int h, const f32x4 v) {
   int r, k;
   small_coords<KCONT>(h, tid, r, k);
+  const int col = r ^ small_swz(k);  // KCONT: k is a multiple of 4, the four k share the swizzle; else r is, and stays one
   if constexpr (KCONT) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) T[(k + c) * SLD + r] = v[c];
+    for (int c = 0; c < 4; c++) T[(k + c) * SLD + col] = v[c];
   } else {
-    *reinterpret_cast<f32x4 *>(&T[k * SLD + r]) = v;
+    *reinterpret_cast<f32x4 *>(&T[k * SLD + col]) = v;
   }
 }
 
@@ -781,6 +808,7 @@ struct FetchCursor {
   __device__ __forceinline__ bool more() const { return idx < total; }
   __device__ __forceinline__ void advance() {
     idx++;
+    if (idx >= total) return;  // stay on the last tile: a fetch past the end re-reads it (and is never stored)
     k0 += SK;
     if (k0 >= K) {
       k0 = 0;
@@ -849,7 +877,14 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
 
   constexpr int Q = SK / 16;  // MFMA steps per quarter of a tile
   static_assert(Q == 2 * SNV, "one LDS-store slice and every other step one global-load slice per chain step");
-  const int aoff = lk * SLD + wm + li, boff = lk * SLD + wn + li;
+  // fragment of step s: row 4s + lk, column (w + li) ^ 4 * (s & 7); s & 7 = the step within its quarter (Q = 8)
+  static_assert(Q == 8, "the swizzle period is one quarter");
+  int aoff[Q], boff[Q];
+#pragma unroll
+  for (int st = 0; st < Q; st++) {
+    aoff[st] = lk * SLD + ((wm + li) ^ (st << 2));
+    boff[st] = lk * SLD + ((wn + li) ^ (st << 2));
+  }
   // Tile t = it + PAR, LDS buffer PAR, in four quarters of 8 chain steps; after each step one slice of other work:
   //   q0, q1  fragments of the next quarter; the global loads of tile t+2 into register stage PAR
   //   q2      fragments of q3; tile t+1 (fetched a tile and a half ago into stage PAR^1) into LDS buffer PAR^1
@@ -863,16 +898,16 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
   if (total > 0) {
 #pragma unroll
     for (int st = 0; st < Q; st++) {
-      fa[0][st] = As[0][aoff + st * 4 * SLD];
-      fb[0][st] = Bs[0][boff + st * 4 * SLD];
+      fa[0][st] = As[0][aoff[st] + st * 4 * SLD];
+      fb[0][st] = Bs[0][boff[st] + st * 4 * SLD];
     }
   }
   auto tile_body = [&](auto par_c, auto steady_c, bool store_rt, bool fetch_rt) {
     constexpr int PAR = decltype(par_c)::value;
     constexpr bool STEADY = decltype(steady_c)::value;
     const bool store_next = STEADY || store_rt, fetch_next = STEADY || fetch_rt;
-    const float *as = As[PAR] + aoff, *bs = Bs[PAR] + boff;
-    const float *an = As[PAR ^ 1] + aoff, *bn = Bs[PAR ^ 1] + boff;
+    const float *as = As[PAR], *bs = Bs[PAR];
+    const float *an = As[PAR ^ 1], *bn = Bs[PAR ^ 1];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int c = q & 1;
@@ -880,11 +915,11 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
       for (int st = 0; st < Q; st++) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][st], fb[c][st], acc, 0, 0, 0);
         if (q + 1 < 4) {  // fragments of the next quarter
-          fa[c ^ 1][st] = as[((q + 1) * Q + st) * 4 * SLD];
-          fb[c ^ 1][st] = bs[((q + 1) * Q + st) * 4 * SLD];
+          fa[c ^ 1][st] = as[aoff[st] + ((q + 1) * Q + st) * 4 * SLD];
+          fb[c ^ 1][st] = bs[boff[st] + ((q + 1) * Q + st) * 4 * SLD];
         } else if (store_next) {  // first fragments of the next tile (its buffer is complete: the barrier is behind us)
-          fa[c ^ 1][st] = an[st * 4 * SLD];
-          fb[c ^ 1][st] = bn[st * 4 * SLD];
+          fa[c ^ 1][st] = an[aoff[st] + st * 4 * SLD];
+          fb[c ^ 1][st] = bn[boff[st] + st * 4 * SLD];
         }
         if (q == 2 && store_next) {  // one vector of the next tile into the other LDS buffer
           if (st & 1) small_store_one<B_KCONT>(Bs[PAR ^ 1], tid, st >> 1, rb[PAR ^ 1][st >> 1]);
@@ -901,7 +936,12 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (q == 2) __syncthreads();
+      if (q == 2) {
+        // the last quarter's fragments are in registers before the barrier (see gemm_mfma16ws_kernel)
+#pragma unroll
+        for (int st = 0; st < Q; st++) asm volatile("" : "+v"(fa[c ^ 1][st]), "+v"(fb[c ^ 1][st]));
+        __syncthreads();
+      }
     }
     if (fetch_next) cur.advance();
   };
@@ -927,6 +967,182 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
       else *dst = epilogue(*dst, acc[r], alpha, beta);
     }
   }
+}
+
+// The same problem with the work SPLIT BY WAVE (FPEMU_GEMM_WS, the default): 512 threads -- waves 0-3 own the four
+// 16x16 chains and issue nothing but their fragment reads and MFMAs; waves 4-7 (one per SIMD, beside a chain wave)
+// do the global loads and the transposing LDS stores, four tiles ahead.  In gemm_mfma16_kernel one wave per SIMD
+// issues all of it in order and a chain step takes ~105 cycles against the 32 of the bare chain (measured:
+// conv weight update, 25 088 steps in 1.1 ms); the instruction streams are now disjoint.  Same LDS layout, same
+// one barrier per tile (after the third quarter: the chain waves then hold their last fragments of buffer PAR,
+// the loader waves have finished buffer PAR^1), same fmaf chain, so the same bits.
+#ifndef FPEMU_ABLATE_WS
+#define FPEMU_ABLATE_WS 0  // timing experiments only: 1 loaders skip the global loads, 2 skip the LDS stores
+#endif
+constexpr int NTW = 2 * NT;
+// MODE 2: whole tiles of aligned operands (unchecked loads); 1: aligned operands, ragged edges (masked vector loads);
+// 0: anything (bounds-checked scalar loads).
+template <bool A_KCONT, bool B_KCONT, bool CHAIN, int MODE>
+__global__ __launch_bounds__(NTW) void gemm_mfma16ws_kernel(Operand A, Operand B, float *C, int64_t ldc,
+                                                            float alpha, float beta, int tiles_m, int tiles_n,
+                                                            Batch bt) {
+  A.p += (int64_t)blockIdx.y * bt.sa;
+  B.p += (int64_t)blockIdx.y * bt.sb;
+  C += (int64_t)blockIdx.y * bt.sc;
+  __shared__ __attribute__((aligned(16))) float As[2][SK * SLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][SK * SLD];
+  int tm, tn;
+  tile_of_block(tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * SB, n0 = tn * SB;
+  const int K = A.K, M = A.R, N = B.R;
+  const int kt = (K + SK - 1) / SK, total = kt * bt.nseg;
+  constexpr int Q = SK / 16;  // MFMA steps per quarter of a tile
+
+  // wave-uniform by construction; readfirstlane makes it a scalar branch, so each barrier below is executed by
+  // exactly the waves of its role
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NT) {
+    // ---- loader waves: tile j travels through register stage j % 4 and LDS buffer j % 2 ----
+    const int tid = threadIdx.x - NT;
+    if (total <= 0) {     // K = 0: nothing to load (the operands may be null); only the chain waves' first barrier
+      __syncthreads();
+      return;
+    }
+    FetchCursor cur{A.p, B.p, 0, 0, total, K, bt.ka, bt.kb};
+    f32x4 ra[4][SNV], rb[4][SNV];
+    // Unconditional: past the last tile the cursor stays where it is and the loads re-read that tile.  With a
+    // conditional fetch the compiler cannot count the loads in flight and waits for ALL of them (vmcnt(0)) before
+    // every LDS store -- the four-tile distance would be gone.
+    auto fetch = [&](f32x4 (&xa)[SNV], f32x4 (&xb)[SNV]) {
+#pragma unroll
+      for (int h = 0; h < SNV; h++) {
+        if constexpr (MODE == 1) {
+          xa[h] = small_load_masked<A_KCONT>(A, cur.a, m0, cur.k0, tid, h);
+          xb[h] = small_load_masked<B_KCONT>(B, cur.b, n0, cur.k0, tid, h);
+        } else {
+          xa[h] = small_load_one<A_KCONT, MODE == 2>(A, cur.a, m0, cur.k0, tid, h);
+          xb[h] = small_load_one<B_KCONT, MODE == 2>(B, cur.b, n0, cur.k0, tid, h);
+        }
+      }
+      cur.advance();
+    };
+    auto store = [&](int buf, const f32x4 (&xa)[SNV], const f32x4 (&xb)[SNV]) {
+#pragma unroll
+      for (int h = 0; h < SNV; h++) {
+        small_store_one<A_KCONT>(As[buf], tid, h, xa[h]);
+        small_store_one<B_KCONT>(Bs[buf], tid, h, xb[h]);
+      }
+    };
+    fetch(ra[0], rb[0]);  // tiles 0 .. 3
+    fetch(ra[1], rb[1]);
+    fetch(ra[2], rb[2]);
+    fetch(ra[3], rb[3]);
+    store(0, ra[0], rb[0]);
+    fetch(ra[0], rb[0]);  // tile 4
+    __syncthreads();      // (the chain waves' first barrier)
+    // during the multiplication of tile `it`: tile it+1 into LDS buffer (it+1) % 2, tile it+5 into the stage it frees
+    auto step = [&](auto s_c, int it) {
+      constexpr int S1 = (decltype(s_c)::value + 1) % 4;
+      if (it + 1 < total) {
+#if !(FPEMU_ABLATE_WS & 2)
+        store((it + 1) & 1, ra[S1], rb[S1]);
+#endif
+#if !(FPEMU_ABLATE_WS & 1)
+        fetch(ra[S1], rb[S1]);
+#endif
+      }
+      __syncthreads();
+    };
+    for (int it = 0; it < total; it += 4) {
+      step(std::integral_constant<int, 0>{}, it);
+      if (it + 1 >= total) break;
+      step(std::integral_constant<int, 1>{}, it + 1);
+      if (it + 2 >= total) break;
+      step(std::integral_constant<int, 2>{}, it + 2);
+      if (it + 3 >= total) break;
+      step(std::integral_constant<int, 3>{}, it + 3);
+    }
+    return;
+  }
+
+  // ---- chain waves ----
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 16, wn = (w & 1) * 16;
+  const int li = lane & 15, lk = lane >> 4;
+  const int col = n0 + wn + li;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (CHAIN) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = m0 + wm + 4 * lk + r;
+      if (row < M && col < N) acc[r] = C[(int64_t)row * ldc + col];
+    }
+  }
+  __syncthreads();  // tile 0 is in LDS buffer 0
+  static_assert(Q == 8, "the swizzle period is one quarter");
+  int aoff[Q], boff[Q];  // fragment of step s: row 4s + lk, column (w + li) ^ 4 * (s & 7)
+#pragma unroll
+  for (int st = 0; st < Q; st++) {
+    aoff[st] = lk * SLD + ((wm + li) ^ (st << 2));
+    boff[st] = lk * SLD + ((wn + li) ^ (st << 2));
+  }
+  float fa[2][Q], fb[2][Q];
+  if (total > 0) {
+#pragma unroll
+    for (int st = 0; st < Q; st++) {
+      fa[0][st] = As[0][aoff[st] + st * 4 * SLD];
+      fb[0][st] = Bs[0][boff[st] + st * 4 * SLD];
+    }
+  }
+  for (int it = 0; it < total; it++) {
+    const float *as = As[it & 1], *bs = Bs[it & 1];
+    const float *an = As[(it & 1) ^ 1], *bn = Bs[(it & 1) ^ 1];
+    const bool more = it + 1 < total;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = q & 1;
+#pragma unroll
+      for (int st = 0; st < Q; st++) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][st], fb[c][st], acc, 0, 0, 0);
+        if (q + 1 < 4) {  // fragments of the next quarter
+          fa[c ^ 1][st] = as[aoff[st] + ((q + 1) * Q + st) * 4 * SLD];
+          fb[c ^ 1][st] = bs[boff[st] + ((q + 1) * Q + st) * 4 * SLD];
+        } else if (more) {  // first fragments of the next tile (its buffer is complete: the barrier is behind us)
+          fa[c ^ 1][st] = an[aoff[st] + st * 4 * SLD];
+          fb[c ^ 1][st] = bn[boff[st] + st * 4 * SLD];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (q == 2) {
+        // The loader waves overwrite this buffer right after the barrier, so the fragments of the last quarter must
+        // BE in registers before it.  Without the pin the compiler sinks their ds_reads (and the quarter's first MFMA)
+        // below the barrier towards their uses -- seen in the ISA, and as a rare wrong 16 x 16 tile on the GPU.
+#pragma unroll
+        for (int st = 0; st < Q; st++) asm volatile("" : "+v"(fa[c ^ 1][st]), "+v"(fb[c ^ 1][st]));
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = m0 + wm + 4 * lk + r;
+    if (MODE == 2 || (row < M && col < N)) {
+      float *dst = C + (int64_t)row * ldc + col;
+      if constexpr (CHAIN) *dst = acc[r];
+      else *dst = epilogue(*dst, acc[r], alpha, beta);
+    }
+  }
+}
+
+#ifndef FPEMU_GEMM_WS
+#define FPEMU_GEMM_WS 1
+#endif
+template <bool CHAIN, int MODE> mfma_fn_t pick_mfma16ws(bool a_kcont, bool b_kcont) {
+  return a_kcont ? (b_kcont ? gemm_mfma16ws_kernel<true, true, CHAIN, MODE> : gemm_mfma16ws_kernel<true, false, CHAIN, MODE>)
+                 : (b_kcont ? gemm_mfma16ws_kernel<false, true, CHAIN, MODE> : gemm_mfma16ws_kernel<false, false, CHAIN, MODE>);
+}
+template <bool CHAIN> mfma_fn_t pick_mfma16ws_mode(int mode, bool a_kcont, bool b_kcont) {
+  return mode == 2 ? pick_mfma16ws<CHAIN, 2>(a_kcont, b_kcont)
+       : mode == 1 ? pick_mfma16ws<CHAIN, 1>(a_kcont, b_kcont) : pick_mfma16ws<CHAIN, 0>(a_kcont, b_kcont);
 }
 
 template <bool CHAIN, bool FULL> mfma_fn_t pick_mfma16(bool a_kcont, bool b_kcont) {
@@ -1000,9 +1216,15 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
                        : (full ? pick_seqk<false, true>(a_kcont, b_kcont) : pick_seqk<false, false>(a_kcont, b_kcont));
     hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, c_vec, alpha, beta, tiles_m, tiles_n, bt);
   } else if (small) {
-    mfma_fn fn = chain ? (full ? pick_mfma16<true, true>(a_kcont, b_kcont) : pick_mfma16<true, false>(a_kcont, b_kcont))
-                       : (full ? pick_mfma16<false, true>(a_kcont, b_kcont) : pick_mfma16<false, false>(a_kcont, b_kcont));
-    hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);
+    if (FPEMU_GEMM_WS) {
+      const int mode = full ? 2 : (a.vec && b.vec) ? 1 : 0;
+      mfma_fn fn = chain ? pick_mfma16ws_mode<true>(mode, a_kcont, b_kcont) : pick_mfma16ws_mode<false>(mode, a_kcont, b_kcont);
+      hipLaunchKernelGGL(fn, grid, dim3(NTW), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);
+    } else {
+      mfma_fn fn = chain ? (full ? pick_mfma16<true, true>(a_kcont, b_kcont) : pick_mfma16<true, false>(a_kcont, b_kcont))
+                         : (full ? pick_mfma16<false, true>(a_kcont, b_kcont) : pick_mfma16<false, false>(a_kcont, b_kcont));
+      hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);
+    }
   } else if (variant == 1) {
     mfma_fn fn = tb == 64 ? pick_mfma_tw<1>(chain, full, a_kcont, b_kcont) : pick_mfma_tw<2>(chain, full, a_kcont, b_kcont);
     hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);

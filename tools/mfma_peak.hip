@@ -45,6 +45,43 @@ __global__ __launch_bounds__(256) void spin_chains(float *out, int iters, float 
   if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NCH>
+__global__ __launch_bounds__(256) void spin_chains16(float *out, int iters, float a0, float b0) {
+  f32x4 acc[NCH];
+  for (int i = 0; i < NCH; i++)
+    for (int r = 0; r < 4; r++) acc[i][r] = 0.f;
+  float a = a0 + threadIdx.x, b = b0;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+#pragma unroll
+      for (int i = 0; i < NCH; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < NCH; i++)
+    for (int r = 0; r < 4; r++) s += acc[i][r];
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+template <int NCH> void run_chains16(float *out, hipEvent_t e0, hipEvent_t e1) {
+  const int iters = 8000;
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(spin_chains16<NCH>, dim3(256), dim3(256), 0, 0, out, iters, 1.0f, 0.5f);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+  }
+  // one wave per SIMD: ns per dependent step = time / (iters * 16 * NCH) when the chains serialise
+  printf("16x16x4: %d chain(s) per wave, 1 wave per SIMD: %.3f ms  %.1f ns per MFMA issued  %.1f TFLOP/s\n", NCH, best,
+         best * 1e6 / (iters * 16.0 * NCH), 1024.0 * iters * 16.0 * NCH * 2048.0 / best / 1e9);
+}
+
 template <int NCH> void run_chains(float *out, hipEvent_t e0, hipEvent_t e1) {
   const int iters = 4000;
   for (int wps = 1; wps <= 4; wps *= 2) {
@@ -84,6 +121,9 @@ int main() {
       printf("%d wave(s) per SIMD: %.3f ms  %.1f TFLOP/s (fp32 MFMA 32x32x2, %d blocks)\n", wps, ms, flop / ms / 1e9, blocks);
     }
   }
+  run_chains16<1>(out, e0, e1);
+  run_chains16<2>(out, e0, e1);
+  run_chains16<4>(out, e0, e1);
   run_chains<1>(out, e0, e1);
   run_chains<2>(out, e0, e1);
   run_chains<4>(out, e0, e1);
