@@ -770,23 +770,6 @@ __device__ __forceinline__ f32x4 small_load_one(const Operand &X, const float *b
   return t;
 }
 
-// Vector-aligned operands (X.vec: base, strides and the contiguous extent are multiples of four elements, so a
-// thread's four elements are inside the operand together or outside together): ONE unconditional 16-byte load from
-// the element's address, or from the tile base when it lies outside, and a select -- no branch, so the compiler can
-// count the loads in flight.
-template <bool KCONT>
-__device__ __forceinline__ f32x4 small_load_masked(const Operand &X, const float *base, int r0, int k0, int tid, int h) {
-  int r, k;
-  small_coords<KCONT>(h, tid, r, k);
-  r += r0;
-  k += k0;
-  const bool in = r < X.R && k < X.K;
-  const float *src = in ? (KCONT ? base + (int64_t)r * X.ld + k : base + (int64_t)k * X.ld + r) : base;
-  const f32x4 t = *reinterpret_cast<const f32x4 *>(src);
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  return in ? t : z;
-}
-
 template <bool KCONT>
 __device__ __forceinline__ void small_store_one(float *T, int tid, int h, const f32x4 v) {
   int r, k;
@@ -969,104 +952,234 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
   }
 }
 
-// The same problem with the work SPLIT BY WAVE (FPEMU_GEMM_WS, the default): 512 threads -- waves 0-3 own the four
-// 16x16 chains and issue nothing but their fragment reads and MFMAs; waves 4-7 (one per SIMD, beside a chain wave)
-// do the global loads and the transposing LDS stores, four tiles ahead.  In gemm_mfma16_kernel one wave per SIMD
-// issues all of it in order and a chain step takes ~105 cycles against the 32 of the bare chain (measured:
-// conv weight update, 25 088 steps in 1.1 ms); the instruction streams are now disjoint.  Same LDS layout, same
-// one barrier per tile (after the third quarter: the chain waves then hold their last fragments of buffer PAR,
-// the loader waves have finished buffer PAR^1), same fmaf chain, so the same bits.
+// The same problem with the work SPLIT BY WAVE (FPEMU_GEMM_WS, the default): the chain waves own the 16x16 chains and
+// issue nothing but their fragment reads and MFMAs; loader waves do the global loads and the transposing LDS stores,
+// WSD tiles ahead.  In gemm_mfma16_kernel one wave per SIMD issues all of it in order and a chain step takes ~105
+// cycles against the 32 of the bare chain (measured: conv weight update, 25 088 steps in 1.1 ms); the instruction
+// streams are now disjoint.  One barrier per tile (after the third quarter: the chain waves then hold their last
+// fragments of buffer PAR, the loader waves have finished buffer PAR^1), same fmaf chain, so the same bits.
+// Two tile sizes (TS): 32 x 32 (four chain waves + 512 loader threads) and 16 x 16 (ONE chain wave + 256 loader
+// threads) for problems with so few chains that 32 x 32 tiles leave most CUs idle: a CU sustains ~35 GB/s of loads
+// that miss to HBM (its outstanding-miss budget over ~1 us), which is 0.93 us per 32 KiB tile against the chain's
+// 0.43 us -- a quarter of the chains per CU halves the bytes per CU and tile.
 #ifndef FPEMU_ABLATE_WS
 #define FPEMU_ABLATE_WS 0  // timing experiments only: 1 loaders skip the global loads, 2 skip the LDS stores
 #endif
-constexpr int NTW = 2 * NT;
+#ifndef FPEMU_GEMM_WS_DEPTH
+#define FPEMU_GEMM_WS_DEPTH 8     // register stages of the loader waves = tiles a load is issued ahead of its LDS store
+#endif
+constexpr int WSD = FPEMU_GEMM_WS_DEPTH;
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+#ifdef FPEMU_WS_TRACE  // tuning builds: s_memtime stamps of workgroup 0's first chain wave and first loader wave, per tile
+__device__ unsigned long long *g_ws_trace = nullptr;
+extern "C" int fpemu_test_ws_trace_(void *ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ws_trace), &ptr, sizeof(ptr)); }
+#define WS_STAMP(slot, it) do { if ((threadIdx.x & 255) == 0 && (it) < 256) ws_stamps[(it) * 8 + (slot)] = (unsigned)__builtin_readcyclecounter(); } while (0)
+#else
+#define WS_STAMP(slot, it) do { } while (0)
+#endif
+
+// Geometry of a TS x TS tile: NC chain waves, NL loader threads in groups of 256; a group covers the tile's
+// [TS][SK] operand image in NPASS = TS * SK / 1024 passes of 256 vectors, group g taking passes g, g + G, ...
+template <int TS> struct WsGeo {
+  static_assert(TS == 32 || TS == 16, "tile side");
+  static constexpr int NC = (TS / 16) * (TS / 16);
+  static constexpr int NL = TS == 32 ? 512 : 256;
+  static constexpr int G = NL / 256;
+  static constexpr int NPASS = TS * SK / 1024;
+  static constexpr int LNV = NPASS / G;       // vectors per operand, tile and loader thread (2 for both sizes)
+  static constexpr int NTHREADS = NC * 64 + NL;
+  static constexpr int WORDS = TS == 32 ? SK * 48 : SK * 16;  // one operand image
+};
+// thread t (0..255) of pass `pass` -> (row r, first k) of its vector: four consecutive k (KCONT) or four rows
+template <bool KCONT, int TS> __device__ __forceinline__ void ws_coords(int pass, int t, int &r, int &k) {
+  if constexpr (TS == 32) {
+    small_coords<KCONT>(pass, t, r, k);
+  } else if constexpr (KCONT) {  // 8 threads per row and 32 k; 16 rows x 64 k per pass
+    r = (t >> 3) & 15;
+    k = pass * 64 + (t >> 7) * 32 + (t & 7) * 4;
+  } else {                        // 4 threads per k; 64 k per pass
+    r = (t & 3) * 4;
+    k = pass * 64 + (t >> 2);
+  }
+}
+// LDS word of element (k, col).  TS = 32: see SLD above.  TS = 16: rows of 16 words, row k at k ^ ((k >> 2) & 1), column
+// XORed with 4 * ((k >> 3) & 3): a fragment read (lanes li < 16, lk < 4 of step s: k = 4s + lk) has bank bit 4 =
+// lk ^ s (mod 2) and the 16 columns permuted, a transposing store (4 rows x 8 k-groups per half-wave) gets bank bit 4
+// from the k-group's low bit and bits 2-3 from its high bits: 32 distinct banks either way.
+template <int TS> __device__ __forceinline__ int ws_word(int k, int col) {
+  if constexpr (TS == 32) return k * SLD + (col ^ small_swz(k));
+  else return ((k ^ ((k >> 2) & 1)) << 4) + (col ^ (((k >> 3) & 3) << 2));
+}
+template <bool KCONT, int TS>
+__device__ __forceinline__ void ws_store_one(float *T, int t, int pass, const f32x4 v) {
+  int r, k;
+  ws_coords<KCONT, TS>(pass, t, r, k);
+  if constexpr (KCONT) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) T[ws_word<TS>(k + c, r)] = v[c];
+  } else {
+    *reinterpret_cast<f32x4 *>(&T[ws_word<TS>(k, r)]) = v;  // r and the XOR are multiples of four: one aligned vector
+  }
+}
+template <bool KCONT, int TS>
+__device__ __forceinline__ f32x4 ws_load_checked(const Operand &X, const float *base, int r0, int k0, int t, int pass) {
+  int r, k;
+  ws_coords<KCONT, TS>(pass, t, r, k);
+  r += r0;
+  k += k0;
+  const float *src = KCONT ? base + (int64_t)r * X.ld + k : base + (int64_t)k * X.ld + r;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  const bool in_outer = KCONT ? (r < X.R) : (k < X.K);
+  const int inner = KCONT ? k : r, inner_end = KCONT ? X.K : X.R;
+  if (in_outer) {
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      if (inner + c < inner_end) v[c] = src[c];
+  }
+  return v;
+}
+
 // MODE 2: whole tiles of aligned operands (unchecked loads); 1: aligned operands, ragged edges (masked vector loads);
 // 0: anything (bounds-checked scalar loads).
-template <bool A_KCONT, bool B_KCONT, bool CHAIN, int MODE>
-__global__ __launch_bounds__(NTW) void gemm_mfma16ws_kernel(Operand A, Operand B, float *C, int64_t ldc,
-                                                            float alpha, float beta, int tiles_m, int tiles_n,
-                                                            Batch bt) {
+template <bool A_KCONT, bool B_KCONT, bool CHAIN, int MODE, int TS>
+__global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Operand A, Operand B, float *C, int64_t ldc,
+                                                                            float alpha, float beta, int tiles_m,
+                                                                            int tiles_n, Batch bt) {
+  using Geo = WsGeo<TS>;
+  constexpr int LNV = Geo::LNV, NCT = Geo::NC * 64;
   A.p += (int64_t)blockIdx.y * bt.sa;
   B.p += (int64_t)blockIdx.y * bt.sb;
   C += (int64_t)blockIdx.y * bt.sc;
-  __shared__ __attribute__((aligned(16))) float As[2][SK * SLD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][SK * SLD];
+  __shared__ __attribute__((aligned(16))) float As[2][Geo::WORDS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][Geo::WORDS];
+#ifdef FPEMU_WS_TRACE
+  __shared__ unsigned ws_stamps[256 * 8];  // stamps go to LDS (cheap, asynchronous) and are dumped once at the end
+#endif
   int tm, tn;
   tile_of_block(tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * SB, n0 = tn * SB;
+  const int m0 = tm * TS, n0 = tn * TS;
   const int K = A.K, M = A.R, N = B.R;
   const int kt = (K + SK - 1) / SK, total = kt * bt.nseg;
   constexpr int Q = SK / 16;  // MFMA steps per quarter of a tile
 
   // wave-uniform by construction; readfirstlane makes it a scalar branch, so each barrier below is executed by
   // exactly the waves of its role
-  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NT) {
-    // ---- loader waves: tile j travels through register stage j % 4 and LDS buffer j % 2 ----
-    const int tid = threadIdx.x - NT;
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NCT) {
+    // ---- loader waves: tile j travels through register stage j % WSD and LDS buffer j % 2 ----
+    const int t = (threadIdx.x - NCT) & 255;   // position within a 256-thread pass of the tile
+    const int g = (threadIdx.x - NCT) >> 8;    // this wave's passes: g, g + G, ... (wave-uniform)
     if (total <= 0) {     // K = 0: nothing to load (the operands may be null); only the chain waves' first barrier
       __syncthreads();
       return;
     }
     FetchCursor cur{A.p, B.p, 0, 0, total, K, bt.ka, bt.kb};
-    f32x4 ra[4][SNV], rb[4][SNV];
-    // Unconditional: past the last tile the cursor stays where it is and the loads re-read that tile.  With a
-    // conditional fetch the compiler cannot count the loads in flight and waits for ALL of them (vmcnt(0)) before
-    // every LDS store -- the four-tile distance would be gone.
-    auto fetch = [&](f32x4 (&xa)[SNV], f32x4 (&xb)[SNV]) {
+    f32x4 ra[WSD][LNV], rb[WSD][LNV];
+    // Aligned operands (MODE 1, 2): this thread's vectors of the tile at (segment 0, k0 = 0) as pointers, set up once;
+    // a tile's addresses are pointer + one UNIFORM offset (scalar arithmetic, one 64-bit add per vector) instead of a
+    // 64-bit multiply per vector per tile.  Rows past the operand's edge are clamped to its last row / last vector:
+    // they only feed outputs that are never stored.  MODE 1 masks k past the segment's end (the one thing that
+    // reaches valid outputs): the lane then reads the tile base and the zero is selected when the stage is STORED
+    // (selecting at the load would make the wave wait for the data it has just asked for).
+    [[maybe_unused]] const float *pa_[LNV], *pb_[LNV];
+    [[maybe_unused]] int ka_[LNV], kb_[LNV];
+    if constexpr (MODE != 0) {
 #pragma unroll
-      for (int h = 0; h < SNV; h++) {
-        if constexpr (MODE == 1) {
-          xa[h] = small_load_masked<A_KCONT>(A, cur.a, m0, cur.k0, tid, h);
-          xb[h] = small_load_masked<B_KCONT>(B, cur.b, n0, cur.k0, tid, h);
-        } else {
-          xa[h] = small_load_one<A_KCONT, MODE == 2>(A, cur.a, m0, cur.k0, tid, h);
-          xb[h] = small_load_one<B_KCONT, MODE == 2>(B, cur.b, n0, cur.k0, tid, h);
+      for (int h = 0; h < LNV; h++) {
+        int r, k;
+        ws_coords<A_KCONT, TS>(g + h * Geo::G, t, r, k);
+        r += m0;
+        if (A_KCONT) r = r < M ? r : M - 1;
+        else r = r < M ? r : M - 4;
+        pa_[h] = A_KCONT ? A.p + (int64_t)r * A.ld + k : A.p + (int64_t)k * A.ld + r;
+        ka_[h] = k;
+        ws_coords<B_KCONT, TS>(g + h * Geo::G, t, r, k);
+        r += n0;
+        if (B_KCONT) r = r < N ? r : N - 1;
+        else r = r < N ? r : N - 4;
+        pb_[h] = B_KCONT ? B.p + (int64_t)r * B.ld + k : B.p + (int64_t)k * B.ld + r;
+        kb_[h] = k;
+      }
+    }
+    // Fetches are UNCONDITIONAL: past the last tile the cursor stays where it is and the loads re-read that tile.
+    // With a conditional fetch the compiler cannot count the loads in flight and waits for ALL of them (vmcnt(0))
+    // before every LDS store -- the prefetch distance would be gone.
+    [[maybe_unused]] unsigned outside[WSD];  // MODE 1: bit h: A's vector h lies past the segment's end; bit 8 + h: B's
+    auto fetch = [&](f32x4 (&xa)[LNV], f32x4 (&xb)[LNV], unsigned &out) {
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int h = 0; h < LNV; h++) {
+          xa[h] = ws_load_checked<A_KCONT, TS>(A, cur.a, m0, cur.k0, t, g + h * Geo::G);
+          xb[h] = ws_load_checked<B_KCONT, TS>(B, cur.b, n0, cur.k0, t, g + h * Geo::G);
+        }
+      } else {
+        const int64_t offa = (cur.a - A.p) + (A_KCONT ? (int64_t)cur.k0 : (int64_t)cur.k0 * A.ld);  // uniform
+        const int64_t offb = (cur.b - B.p) + (B_KCONT ? (int64_t)cur.k0 : (int64_t)cur.k0 * B.ld);
+#pragma unroll
+        for (int h = 0; h < LNV; h++) {
+          if constexpr (MODE == 2) {
+            xa[h] = *reinterpret_cast<const f32x4 *>(pa_[h] + offa);
+            xb[h] = *reinterpret_cast<const f32x4 *>(pb_[h] + offb);
+          } else {
+            const bool ina = ka_[h] + cur.k0 < K, inb = kb_[h] + cur.k0 < K;
+            xa[h] = *reinterpret_cast<const f32x4 *>(ina ? pa_[h] + offa : cur.a);
+            xb[h] = *reinterpret_cast<const f32x4 *>(inb ? pb_[h] + offb : cur.b);
+            if (h == 0) out = 0u;
+            out |= (ina ? 0u : 1u << h) | (inb ? 0u : 256u << h);
+          }
         }
       }
       cur.advance();
     };
-    auto store = [&](int buf, const f32x4 (&xa)[SNV], const f32x4 (&xb)[SNV]) {
+    auto store = [&](int buf, const f32x4 (&xa)[LNV], const f32x4 (&xb)[LNV], unsigned out) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int h = 0; h < SNV; h++) {
-        small_store_one<A_KCONT>(As[buf], tid, h, xa[h]);
-        small_store_one<B_KCONT>(Bs[buf], tid, h, xb[h]);
+      for (int h = 0; h < LNV; h++) {
+        ws_store_one<A_KCONT, TS>(As[buf], t, g + h * Geo::G, (MODE == 1 && ((out >> h) & 1u)) ? z : xa[h]);
+        ws_store_one<B_KCONT, TS>(Bs[buf], t, g + h * Geo::G, (MODE == 1 && ((out >> (8 + h)) & 1u)) ? z : xb[h]);
       }
     };
-    fetch(ra[0], rb[0]);  // tiles 0 .. 3
-    fetch(ra[1], rb[1]);
-    fetch(ra[2], rb[2]);
-    fetch(ra[3], rb[3]);
-    store(0, ra[0], rb[0]);
-    fetch(ra[0], rb[0]);  // tile 4
+    static_for<WSD>([&](auto s_c) {  // tiles 0 .. WSD-1
+      fetch(ra[decltype(s_c)::value], rb[decltype(s_c)::value], outside[decltype(s_c)::value]);
+    });
+    store(0, ra[0], rb[0], outside[0]);
+    fetch(ra[0], rb[0], outside[0]);  // tile WSD
     __syncthreads();      // (the chain waves' first barrier)
-    // during the multiplication of tile `it`: tile it+1 into LDS buffer (it+1) % 2, tile it+5 into the stage it frees
+    // during the multiplication of tile `it`: tile it+1 into LDS buffer (it+1) % 2, tile it+1+WSD into the stage it frees
     auto step = [&](auto s_c, int it) {
-      constexpr int S1 = (decltype(s_c)::value + 1) % 4;
+      constexpr int S1 = (decltype(s_c)::value + 1) % WSD;
+      WS_STAMP(4, it);
       if (it + 1 < total) {
 #if !(FPEMU_ABLATE_WS & 2)
-        store((it + 1) & 1, ra[S1], rb[S1]);
+        store((it + 1) & 1, ra[S1], rb[S1], outside[S1]);
 #endif
+        WS_STAMP(5, it);
 #if !(FPEMU_ABLATE_WS & 1)
-        fetch(ra[S1], rb[S1]);
+        fetch(ra[S1], rb[S1], outside[S1]);
 #endif
       }
+      WS_STAMP(6, it);
       __syncthreads();
+      WS_STAMP(7, it);
     };
-    for (int it = 0; it < total; it += 4) {
-      step(std::integral_constant<int, 0>{}, it);
-      if (it + 1 >= total) break;
-      step(std::integral_constant<int, 1>{}, it + 1);
-      if (it + 2 >= total) break;
-      step(std::integral_constant<int, 2>{}, it + 2);
-      if (it + 3 >= total) break;
-      step(std::integral_constant<int, 3>{}, it + 3);
+    for (int it = 0; it < total; it += WSD) {
+      bool done = false;  // uniform
+      static_for<WSD>([&](auto s_c) {
+        if (done) return;
+        step(s_c, it + decltype(s_c)::value);
+        done = it + decltype(s_c)::value + 1 >= total;
+      });
     }
     return;
   }
 
   // ---- chain waves ----
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 16, wn = (w & 1) * 16;
+  const int wm = TS == 32 ? (w >> 1) * 16 : 0, wn = TS == 32 ? (w & 1) * 16 : 0;
   const int li = lane & 15, lk = lane >> 4;
   const int col = n0 + wn + li;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1078,25 +1191,26 @@ __global__ __launch_bounds__(NTW) void gemm_mfma16ws_kernel(Operand A, Operand B
     }
   }
   __syncthreads();  // tile 0 is in LDS buffer 0
-  static_assert(Q == 8, "the swizzle period is one quarter");
-  int aoff[Q], boff[Q];  // fragment of step s: row 4s + lk, column (w + li) ^ 4 * (s & 7)
+  static_assert(Q == 8, "the swizzles have a period of one quarter (8 steps)");
+  // fragment of step s = 8q + st: element (4s + lk, w + li); its word is that of step st plus s - st whole steps
+  constexpr int STEP = TS == 32 ? 4 * SLD : 4 * 16;
+  int aoff[Q], boff[Q];
 #pragma unroll
   for (int st = 0; st < Q; st++) {
-    aoff[st] = lk * SLD + ((wm + li) ^ (st << 2));
-    boff[st] = lk * SLD + ((wn + li) ^ (st << 2));
+    aoff[st] = ws_word<TS>(4 * st + lk, wm + li) - st * STEP;
+    boff[st] = ws_word<TS>(4 * st + lk, wn + li) - st * STEP;
   }
   float fa[2][Q], fb[2][Q];
   if (total > 0) {
 #pragma unroll
     for (int st = 0; st < Q; st++) {
-      fa[0][st] = As[0][aoff[st] + st * 4 * SLD];
-      fb[0][st] = Bs[0][boff[st] + st * 4 * SLD];
+      fa[0][st] = As[0][aoff[st] + st * STEP];
+      fb[0][st] = Bs[0][boff[st] + st * STEP];
     }
   }
   for (int it = 0; it < total; it++) {
     const float *as = As[it & 1], *bs = Bs[it & 1];
     const float *an = As[(it & 1) ^ 1], *bn = Bs[(it & 1) ^ 1];
-    const bool more = it + 1 < total;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int c = q & 1;
@@ -1104,21 +1218,26 @@ __global__ __launch_bounds__(NTW) void gemm_mfma16ws_kernel(Operand A, Operand B
       for (int st = 0; st < Q; st++) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][st], fb[c][st], acc, 0, 0, 0);
         if (q + 1 < 4) {  // fragments of the next quarter
-          fa[c ^ 1][st] = as[aoff[st] + ((q + 1) * Q + st) * 4 * SLD];
-          fb[c ^ 1][st] = bs[boff[st] + ((q + 1) * Q + st) * 4 * SLD];
-        } else if (more) {  // first fragments of the next tile (its buffer is complete: the barrier is behind us)
-          fa[c ^ 1][st] = an[aoff[st] + st * 4 * SLD];
-          fb[c ^ 1][st] = bn[boff[st] + st * 4 * SLD];
+          fa[c ^ 1][st] = as[aoff[st] + ((q + 1) * Q + st) * STEP];
+          fb[c ^ 1][st] = bs[boff[st] + ((q + 1) * Q + st) * STEP];
+        } else {  // first fragments of the next tile (its buffer is complete: the barrier is behind us).  Unconditional:
+                  // after the last tile they are stale words nobody uses, and a branch here costs the compiler its
+                  // count of LDS reads in flight (lgkmcnt(0) at the top of every tile)
+          fa[c ^ 1][st] = an[aoff[st] + st * STEP];
+          fb[c ^ 1][st] = bn[boff[st] + st * STEP];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (q == 0) WS_STAMP(0, it);
       if (q == 2) {
         // The loader waves overwrite this buffer right after the barrier, so the fragments of the last quarter must
         // BE in registers before it.  Without the pin the compiler sinks their ds_reads (and the quarter's first MFMA)
         // below the barrier towards their uses -- seen in the ISA, and as a rare wrong 16 x 16 tile on the GPU.
 #pragma unroll
         for (int st = 0; st < Q; st++) asm volatile("" : "+v"(fa[c ^ 1][st]), "+v"(fb[c ^ 1][st]));
+        WS_STAMP(1, it);
         __syncthreads();
+        WS_STAMP(2, it);
       }
     }
   }
@@ -1131,18 +1250,26 @@ __global__ __launch_bounds__(NTW) void gemm_mfma16ws_kernel(Operand A, Operand B
       else *dst = epilogue(*dst, acc[r], alpha, beta);
     }
   }
+#ifdef FPEMU_WS_TRACE
+  if (g_ws_trace && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {  // loaders have long finished
+    for (int i = threadIdx.x; i < 256 * 8; i += 64) g_ws_trace[i] = ws_stamps[i];
+  }
+#endif
 }
 
 #ifndef FPEMU_GEMM_WS
 #define FPEMU_GEMM_WS 1
 #endif
-template <bool CHAIN, int MODE> mfma_fn_t pick_mfma16ws(bool a_kcont, bool b_kcont) {
-  return a_kcont ? (b_kcont ? gemm_mfma16ws_kernel<true, true, CHAIN, MODE> : gemm_mfma16ws_kernel<true, false, CHAIN, MODE>)
-                 : (b_kcont ? gemm_mfma16ws_kernel<false, true, CHAIN, MODE> : gemm_mfma16ws_kernel<false, false, CHAIN, MODE>);
+#ifndef FPEMU_GEMM_WS_TINY
+#define FPEMU_GEMM_WS_TINY 128   // fewer 32 x 32 tiles than this (per launch): 16 x 16 tiles
+#endif
+template <bool CHAIN, int MODE, int TS> mfma_fn_t pick_mfma16ws(bool a_kcont, bool b_kcont) {
+  return a_kcont ? (b_kcont ? gemm_mfma16ws_kernel<true, true, CHAIN, MODE, TS> : gemm_mfma16ws_kernel<true, false, CHAIN, MODE, TS>)
+                 : (b_kcont ? gemm_mfma16ws_kernel<false, true, CHAIN, MODE, TS> : gemm_mfma16ws_kernel<false, false, CHAIN, MODE, TS>);
 }
-template <bool CHAIN> mfma_fn_t pick_mfma16ws_mode(int mode, bool a_kcont, bool b_kcont) {
-  return mode == 2 ? pick_mfma16ws<CHAIN, 2>(a_kcont, b_kcont)
-       : mode == 1 ? pick_mfma16ws<CHAIN, 1>(a_kcont, b_kcont) : pick_mfma16ws<CHAIN, 0>(a_kcont, b_kcont);
+template <bool CHAIN, int TS> mfma_fn_t pick_mfma16ws_mode(int mode, bool a_kcont, bool b_kcont) {
+  return mode == 2 ? pick_mfma16ws<CHAIN, 2, TS>(a_kcont, b_kcont)
+       : mode == 1 ? pick_mfma16ws<CHAIN, 1, TS>(a_kcont, b_kcont) : pick_mfma16ws<CHAIN, 0, TS>(a_kcont, b_kcont);
 }
 
 template <bool CHAIN, bool FULL> mfma_fn_t pick_mfma16(bool a_kcont, bool b_kcont) {
@@ -1202,7 +1329,10 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   const int64_t t32 = ((M + 31) / 32) * ((N + 31) / 32) * batch;
   const bool small = variant == 1 && t64 < 256 && t32 <= 320;  // up to ~1.25 waves per SIMD (measured: at 576 tiles
                                                                // the 64 x 64 kernel is the faster one again)
-  const int tb = small ? SB : (variant == 1 && (t128 < 512 || M <= 64 || N <= 64)) ? 64 : 128;
+  // so few chains that even 32 x 32 tiles leave most CUs idle: 16 x 16 tiles, one chain per workgroup (a CU's load
+  // rate, not the chain, bounds a 32 x 32 tile: see gemm_mfma16ws_kernel)
+  const bool tiny = small && FPEMU_GEMM_WS && t32 < FPEMU_GEMM_WS_TINY;
+  const int tb = tiny ? 16 : small ? SB : (variant == 1 && (t128 < 512 || M <= 64 || N <= 64)) ? 64 : 128;
   const int tiles_m = (int)((M + tb - 1) / tb), tiles_n = (int)((N + tb - 1) / tb);
   const int64_t nwg = (int64_t)tiles_m * tiles_n;
   if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "too many tiles");
@@ -1218,8 +1348,13 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   } else if (small) {
     if (FPEMU_GEMM_WS) {
       const int mode = full ? 2 : (a.vec && b.vec) ? 1 : 0;
-      mfma_fn fn = chain ? pick_mfma16ws_mode<true>(mode, a_kcont, b_kcont) : pick_mfma16ws_mode<false>(mode, a_kcont, b_kcont);
-      hipLaunchKernelGGL(fn, grid, dim3(NTW), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);
+      if (tiny) {
+        mfma_fn fn = chain ? pick_mfma16ws_mode<true, 16>(mode, a_kcont, b_kcont) : pick_mfma16ws_mode<false, 16>(mode, a_kcont, b_kcont);
+        hipLaunchKernelGGL(fn, grid, dim3(WsGeo<16>::NTHREADS), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);
+      } else {
+        mfma_fn fn = chain ? pick_mfma16ws_mode<true, 32>(mode, a_kcont, b_kcont) : pick_mfma16ws_mode<false, 32>(mode, a_kcont, b_kcont);
+        hipLaunchKernelGGL(fn, grid, dim3(WsGeo<32>::NTHREADS), 0, s, a, b, C, ldc, alpha, beta, tiles_m, tiles_n, bt);
+      }
     } else {
       mfma_fn fn = chain ? (full ? pick_mfma16<true, true>(a_kcont, b_kcont) : pick_mfma16<true, false>(a_kcont, b_kcont))
                          : (full ? pick_mfma16<false, true>(a_kcont, b_kcont) : pick_mfma16<false, false>(a_kcont, b_kcont));

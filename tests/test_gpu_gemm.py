@@ -48,6 +48,8 @@ def test_gemm_vs_reference_fixture(hip, bname, variant, fused):
                                    # few outputs, long k: the 16x16x4 chain kernel, odd / even tile counts,
                                    # whole tiles and ragged ones (steady loop + every tail form)
                                    (96, 160, 1664), (50, 70, 1500), (32, 32, 640), (33, 31, 129),
+                                   # 128 .. 320 tiles of 32 x 32: the four-chain form of that kernel (fewer: one chain per workgroup)
+                                   (384, 384, 256), (380, 372, 200), (16, 16, 4096), (48, 20, 130),
                                    (2950, 2944, 70), (2944, 2944, 64)])   # >= 512 tiles: the 128 x 128 kernels
 @pytest.mark.parametrize("at,bt", [(False, False), (True, False), (False, True), (True, True)])
 def test_gemm_vs_oracle(hip, bname, variant, fused, shape, at, bt):

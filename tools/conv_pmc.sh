@@ -13,11 +13,11 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_IN
 timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE \
   --output-format csv -d $OUT/c -- python3 tools/conv_bench.py $SHAPE > $OUT/c.log 2>&1 || { tail -5 $OUT/c.log; }
 python3 - $OUT <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, os
 acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "gemm_mfma_conv" in r["Kernel_Name"]:
+        if os.environ.get("KERNEL", "gemm_mfma_conv") in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 v = {k: sum(x) / len(x) for k, x in acc.items()}
 for k in sorted(v):
