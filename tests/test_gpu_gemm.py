@@ -161,3 +161,34 @@ def test_gemm_chain_k_segments_and_batch(hip, variant, fused):
         assert_bits_equal(tC[b].cpu().numpy(), want, "chain batch %d" % b)
     assert L.fpemu_gemm_chain_f32(tC.data_ptr(), tA.data_ptr(), tB.data_ptr(), M, N, K, K, N, N, 0, 0, variant,
                                   1, 0, 0, 0, 0, 0, 0, None) == -1   # k_segments < 1
+
+
+@pytest.mark.parametrize("M,N,K,nseg,nb", [
+    (64, 96, 128, 3, 2),      # 16 x 16 tiles, whole tiles of aligned operands (unchecked loads)
+    (60, 100, 132, 3, 2),     # 16 x 16 tiles, aligned operands with ragged edges in M, N and k (masked loads)
+    (61, 99, 130, 2, 1),      # 16 x 16 tiles, unaligned (checked scalar loads)
+    (256, 320, 128, 2, 2),    # 32 x 32 tiles (160 of them), whole
+    (252, 316, 136, 2, 2),    # 32 x 32 tiles, ragged, aligned
+    (250, 318, 70, 3, 2),     # 32 x 32 tiles, unaligned
+    (16, 16, 3136, 8, 1),     # one chain, many ragged segments (the conv weight update's k = OH * OW per image)
+])
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_chain_kernel_forms_vs_oracle(hip, M, N, K, nseg, nb, at, bt):
+    """The wave-specialised small-tile kernels behind fpemu_gemm_chain_f32, every load mode and both tile sizes, with k
+    segments and batch: chain from C = 0 equals the oracle's GEMM over the concatenated k."""
+    rng = np.random.default_rng(M * 31 + N * 7 + K + nseg)
+    A = rng.standard_normal((nb, nseg, K, M) if at else (nb, nseg, M, K)).astype(np.float32)
+    B = rng.standard_normal((nb, nseg, N, K) if bt else (nb, nseg, K, N)).astype(np.float32)
+    A.flat[::53] = 0.0
+    tA, tB = _t(A), _t(B)
+    tC = torch.zeros(nb, M, N, device=DEV)
+    L = hip.lib()
+    lda, ldb = (M if at else K), (K if bt else N)
+    rc = L.fpemu_gemm_chain_f32(tC.data_ptr(), tA.data_ptr(), tB.data_ptr(), M, N, K, lda, ldb, N, at, bt, 1,
+                                nb, nseg * M * K, nseg * K * N, M * N, nseg, M * K, K * N, None)
+    assert rc == 0, L.fpemu_last_error()
+    got = tC.cpu().numpy()
+    for b in range(nb):
+        Acat = np.concatenate([A[b, s].T if at else A[b, s] for s in range(nseg)], axis=1)   # [M, nseg * K]
+        Bcat = np.concatenate([B[b, s].T if bt else B[b, s] for s in range(nseg)], axis=0)   # [nseg * K, N]
+        assert_bits_equal(got[b], orc.gemm(Acat, Bcat, 1.0, False, False, fused=True), "chain %s batch %d" % ((M, N, K, nseg, at, bt), b))
