@@ -555,7 +555,22 @@ def main():
                 fl = 2.0 * N_ * K_ * H_ * H_ * C_ * 9
                 extras["conv_fp_3x3_c64_56"] = {"ms": round(c_avg, 5), "TFLOP/s_effective": round(fl / (c_avg * 1e-3) / 1e12, 2),
                                                 "verified": verified["conv_fp_3x3_c64_56"]}
-                del ci, cw, cb, co
+                # the weight update of the same layer: a chain over all N * OH * OW products per weight (small-tile chain GEMM)
+                go = torch.randn(N_, K_, H_, H_, device=dev)
+                gw = torch.empty_like(cw)
+
+                def wu_step():
+                    hip.conv2d_wu_(gw, go, ci, 1, 1)
+
+                wu_step()
+                w_avg, _ = time_launches(wu_step, 5)
+                gw2 = torch.empty_like(cw)
+                hip.conv2d_wu_(gw2, go[:2].contiguous(), ci[:2].contiguous(), 1, 1)  # two images: what the oracle checks in seconds
+                want = orc.conv2d_wu(go[:2].cpu().numpy(), ci[:2].cpu().numpy(), (3, 3), 1, 1, fused=True)
+                verified["conv_wu_3x3_c64_56"] = same(gw2, want)
+                extras["conv_wu_3x3_c64_56"] = {"ms": round(w_avg, 5), "TFLOP/s_effective": round(fl / (w_avg * 1e-3) / 1e12, 2),
+                                                "verified": verified["conv_wu_3x3_c64_56"], "verified_on": "2 of the 32 images (same kernel)"}
+                del ci, cw, cb, co, go, gw, gw2
             except Exception as e:  # the conv leg must never take the bench line down
                 extras["conv_fp_3x3_c64_56"] = "failed: %r" % (e,)
                 verified["conv_fp_3x3_c64_56"] = False
