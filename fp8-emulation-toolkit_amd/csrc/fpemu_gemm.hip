@@ -337,6 +337,9 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 #ifndef FPEMU_GEMM_PIPE
 #define FPEMU_GEMM_PIPE 1
 #endif
+#ifndef FPEMU_CONV_T128_MIN
+#define FPEMU_CONV_T128_MIN 512   // implicit convolution: 128 x 128 tiles when at least this many exist
+#endif
 #ifndef FPEMU_GEMM_WAVES
 #define FPEMU_GEMM_WAVES 2
 #endif
@@ -346,6 +349,13 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 // kj, ki) of 64 channels each: B advances by 1 (next ki), Wp - (S-1) (next kj) or the channel-block step.
 // Columns with ox' >= OW (or q >= nvalid) are garbage positions: computed and dropped.  Accumulators start at
 // bias[row] (or +0) and C = acc, as in CHAIN mode.
+#ifdef FPEMU_GEMM_TRACE  // tuning builds (tools/conv_trace.py): per-workgroup phase stamps (100 MHz) of the conv GEMM
+__device__ unsigned long long *g_conv_phase = nullptr;
+extern "C" int fpemu_test_conv_phase_(void *ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_phase), &ptr, sizeof(ptr)); }
+#define CONV_STAMP(var) [[maybe_unused]] const unsigned long long var = CONV ? wall_clock64() : 0ull
+#else
+#define CONV_STAMP(var) do { } while (0)
+#endif
 struct ConvMap {
   const float *bias;  // nullptr: start at +0
   int S, R, Wp;       // filter taps per row / rows, padded row pitch
@@ -372,6 +382,7 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
   const int li = lane & 31, lk = lane >> 5;
   const int K = A.K;
 
+  CONV_STAMP(ts0);
   f32x16 acc[TW][TW];
 #pragma unroll
   for (int i = 0; i < TW; i++)
@@ -421,6 +432,7 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
   tile_store<B_KCONT, MBK, TB>(Bs[0], tid, pb);
   __syncthreads();
 
+  CONV_STAMP(ts1);  // first tile in LDS
   [[maybe_unused]] int cur = 0;
   const int kt = (K + MBK - 1) / MBK, total = kt * bt.nseg;
   int nk0 = 0;  // k offset of the tile being prefetched
@@ -622,6 +634,7 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
 
 #endif
 
+  CONV_STAMP(ts2);  // k loop done
   [[maybe_unused]] const int M = A.R, N = B.R;
   if constexpr (CONV) {
 #pragma unroll
@@ -639,6 +652,15 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
           }
       }
     }
+#ifdef FPEMU_GEMM_TRACE
+    if (threadIdx.x == 0 && g_conv_phase != nullptr) {
+      const unsigned long long idx = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+      g_conv_phase[4 * idx] = ts0;
+      g_conv_phase[4 * idx + 1] = ts1;
+      g_conv_phase[4 * idx + 2] = ts2;
+      g_conv_phase[4 * idx + 3] = wall_clock64();
+    }
+#endif
   } else if constexpr (CHAIN) {
 #pragma unroll
     for (int i = 0; i < TW; i++)
@@ -1380,7 +1402,7 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
 // Tile edge fpemu_gemm_conv_launch_ will pick (callers size the operand's read-ahead slack by it).
 extern "C" int fpemu_gemm_conv_tile_(int64_t M, int64_t nvalid, int64_t batch) {
   const int64_t t128 = (M / 128) * ((nvalid + 127) / 128) * batch;
-  return (M % 128 == 0 && t128 >= 512) ? 128 : 64;
+  return (M % 128 == 0 && t128 >= FPEMU_CONV_T128_MIN) ? 128 : 64;
 }
 
 extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float *xp, const float *bias, int64_t batch,

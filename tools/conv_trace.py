@@ -26,10 +26,23 @@ for _ in range(3):
     hip.conv2d_fp_(y, x, w, b, st, pd)
 torch.cuda.synchronize()
 trace = torch.zeros(3 * 65536, dtype=torch.int64, device="cuda")
+phase = torch.zeros(4 * 65536, dtype=torch.int64, device="cuda")
+L.fpemu_test_conv_phase_.argtypes = [ctypes.c_void_p]
+L.fpemu_test_conv_phase_.restype = ctypes.c_int
 assert L.fpemu_test_conv_trace_(trace.data_ptr()) == 0
+assert L.fpemu_test_conv_phase_(phase.data_ptr()) == 0
 hip.conv2d_fp_(y, x, w, b, st, pd)
 torch.cuda.synchronize()
 L.fpemu_test_conv_trace_(None)
+L.fpemu_test_conv_phase_(None)
+ph = phase.cpu().numpy().reshape(-1, 4)
+ph = ph[ph[:, 0] != 0].astype(np.float64) / 100.0
+first = ph[:, 0] < ph[:, 0].min() + 10.0
+for name, sel in (("first round (started within 10 us)", first), ("later rounds", ~first)):
+    if sel.any():
+        q = ph[sel]
+        print("%s: %d workgroups; prologue (entry -> first tile in LDS) %.1f us, k loop %.1f us, epilogue %.1f us (medians)" % (
+            name, sel.sum(), np.median(q[:, 1] - q[:, 0]), np.median(q[:, 2] - q[:, 1]), np.median(q[:, 3] - q[:, 2])))
 t = trace.cpu().numpy().reshape(-1, 3)
 t = t[t[:, 0] != 0]
 t0, t1, hw = t[:, 0], t[:, 1], t[:, 2]
