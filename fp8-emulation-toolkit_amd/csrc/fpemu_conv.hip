@@ -243,6 +243,22 @@ __global__ __launch_bounds__(NT) void pad_planes(const float *__restrict__ x, fl
 // ki ascending, o2) directly, taking only the taps that exist (the reference does the same; a missing tap
 // contributes nothing).  Lanes of a wave hold pixels x = xi * stride + phase of one row and one phase, so which
 // (kj, ki) taps exist is uniform over the wave: the weights are scalar loads and gout is read coalesced.
+// Wfew[(ob, kj, ki)][o2][c] = w[ob*KB + o2][c][kj][ki]: the U * C weights of a batch of chain steps are contiguous,
+// so they arrive as a few wide scalar loads (in the tensor's own layout every one is a scalar load of its own, from
+// a cache line of its own: 37 KB of weights walked by every wave through a 16 KB scalar cache).
+__global__ __launch_bounds__(NT) void pack_w_few(const float *__restrict__ w, float *__restrict__ Wm, Geo g) {
+  const int64_t total = g.K * g.C * g.R * g.S;
+  for (int64_t i = gtid(); i < total; i += gstride()) {
+    int64_t kk = i;
+    const int64_t c = kk % g.C; kk /= g.C;
+    const int64_t o2 = kk % g.KB; kk /= g.KB;
+    const int64_t ki = kk % g.S; kk /= g.S;
+    const int64_t kj = kk % g.R;
+    const int64_t ob = kk / g.R;
+    Wm[i] = w[(((ob * g.KB + o2) * g.C + c) * g.R + kj) * g.S + ki];
+  }
+}
+
 struct FewGeo {  // 32-bit throughout: one image's tensors are far below 2^31 elements
   int st, pad, R, S, OH, OW, K, H, W, KB;
 };
@@ -250,7 +266,11 @@ struct FewGeo {  // 32-bit throughout: one image's tensors are far below 2^31 el
 #ifndef FPEMU_FEW_ROWS
 #define FPEMU_FEW_ROWS 1
 #endif
-constexpr int kFewRows = FPEMU_FEW_ROWS;  // rows y, y + stride, ... per lane (they share the filter rows); measured on the first ResNet layer: 1 -> 1.69 ms, 2 -> 1.86, 4 -> 2.34 (too few waves left to hide the load latency)
+#ifndef FPEMU_FEW_UNROLL
+#define FPEMU_FEW_UNROLL 8
+#endif
+constexpr int kFewUnroll = FPEMU_FEW_UNROLL;  // output channels per batch of gout loads; measured 4 -> 0.402 ms, 8 -> 0.364, 16 -> 0.387
+constexpr int kFewRows = FPEMU_FEW_ROWS;  // rows y, y + stride, ... per lane (they share the filter rows); measured on the first ResNet layer (batch 32): 1 -> 0.364 ms, 2 -> 0.46 (too few waves left to hide the load latency)
 
 template <bool FUSED, int CC>
 __global__ __launch_bounds__(NT) void bp_few_channels(const float *__restrict__ go, const float *__restrict__ w,
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(NT) void bp_few_channels(const float *__restrict__ 
   const int r = by % st;                       // y = (yb * TR + t) * st + r
   const int yb = by / st;
   const int xi = bx * blockDim.x + threadIdx.x, x = xi * st + phase;   // blockDim.x: 64 / 128 / 256
-  const int plane = OH * OW, RS = R * S, wstep = CC * RS;
+  const int plane = OH * OW;
   float acc[TR][CC];
 #pragma unroll
   for (int t = 0; t < TR; t++)
@@ -291,32 +311,70 @@ __global__ __launch_bounds__(NT) void bp_few_channels(const float *__restrict__ 
   for (int ob = 0; ob < g.K; ob += g.KB)
     for (int kj = kjmax; kj >= 0; kj -= st) {
       const int ojb = yb * TR + (r + pad - kj) / st;   // exact: r + pad - kj is a multiple of st (may be negative)
+      bool okt[TR], any = false;
+#pragma unroll
+      for (int t = 0; t < TR; t++) {
+        okt[t] = ojb + t >= 0 && ojb + t < OH;   // uniform
+        any = any || okt[t];
+      }
+      if (!any) continue;                          // before the channel loop: a branch inside it serialises the loads
       for (int ki = 0; ki < S; ki++) {
         const int d = phase + pad - ki;
         const int dq = d / st;
         if (dq * st != d) continue;                // uniform: this tap does not exist for this phase
         const int oi = xi + dq;
         if (!(x < g.W && oi >= 0 && oi < OW)) continue;   // per lane, once per tap
-        const float *wp = w + ((ob * CC * R + kj) * S + ki);
+        const float *wp = w + (((ob / g.KB) * R + kj) * S + ki) * (g.KB * CC);   // packed: [o2][c] of this tap
         const float *sp = gon + ((ob * OH + ojb) * OW + oi);
-        bool okt[TR];
+        int toff[TR];                              // a missing row reads row ojb's neighbour that exists; its sum is dropped
 #pragma unroll
-        for (int t = 0; t < TR; t++) okt[t] = ojb + t >= 0 && ojb + t < OH;   // uniform
-#pragma unroll 8
-        for (int o2 = 0; o2 < g.KB; o2++) {
-          float wv[CC];
+        for (int t = 0; t < TR; t++) toff[t] = (okt[t] ? t : (ojb < 0 ? -ojb : OH - 1 - ojb)) * OW;
+        // U output channels at a time: their gout values are loaded one batch ahead of the batch whose U * CC chain
+        // steps are running (2 * U loads in flight per lane; the weights are wide scalar loads that hit their cache)
+        auto fetch = [&](auto &gv, int o2) {
+          constexpr int U = sizeof(gv) / sizeof(gv[0]);
 #pragma unroll
-          for (int c = 0; c < CC; c++) wv[c] = wp[o2 * wstep + c * RS];
+          for (int u = 0; u < U; u++)
 #pragma unroll
-          for (int t = 0; t < TR; t++) {
-            if (!okt[t]) continue;
-            const float gv = sp[o2 * plane + t * OW];
+            for (int t = 0; t < TR; t++) gv[u][t] = sp[(o2 + u) * plane + toff[t]];
+        };
+        auto steps = [&](const auto &gv, int o2) {
+          constexpr int U = sizeof(gv) / sizeof(gv[0]);
+          float wv[U][CC];
 #pragma unroll
-            for (int c = 0; c < CC; c++) {
-              if constexpr (FUSED) acc[t][c] = __builtin_fmaf(wv[c], gv, acc[t][c]);
-              else acc[t][c] = acc[t][c] + wv[c] * gv;   // -ffp-contract=off: product and sum rounded separately
-            }
+          for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int c = 0; c < CC; c++) wv[u][c] = wp[(o2 + u) * CC + c];
+#pragma unroll
+          for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int t = 0; t < TR; t++)
+#pragma unroll
+              for (int c = 0; c < CC; c++) {
+                float a;
+                if constexpr (FUSED) a = __builtin_fmaf(wv[u][c], gv[u][t], acc[t][c]);
+                else a = acc[t][c] + wv[u][c] * gv[u][t];   // -ffp-contract=off: product and sum rounded separately
+                acc[t][c] = okt[t] ? a : acc[t][c];
+              }
+        };
+        constexpr int U = kFewUnroll;
+        const int nb = g.KB / U;
+        if (nb > 0) {
+          float ga[U][TR], gb[U][TR];
+          fetch(ga, 0);
+          int b = 0;
+          for (; b + 2 <= nb; b += 2) {
+            fetch(gb, (b + 1) * U);
+            steps(ga, b * U);
+            fetch(ga, (b + 2 < nb ? b + 2 : nb - 1) * U);   // unconditional (the last one re-reads a batch): a
+            steps(gb, (b + 1) * U);                         // load under a branch costs the counted waits
           }
+          if (b < nb) steps(ga, b * U);
+        }
+        for (int o2 = nb * U; o2 < g.KB; o2++) {
+          float g1[1][TR];
+          fetch(g1, o2);
+          steps(g1, o2);
         }
       }
     }
@@ -556,13 +614,14 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
   float *Wm = (float *)ws, *cols = Wm + wf;
   const int64_t HW = H * W, krs = K * R * S, P = g.OH * g.OW;
   if (C <= 4 && N <= 65535 && (H + stride) * stride <= 65535 && (variant == 0 || variant == 1) &&
-      K * g.OH * g.OW <= 0x7FFFFFFF && C * H * W <= 0x7FFFFFFF) {
+      K * g.OH * g.OW <= 0x7FFFFFFF && C * H * W <= 0x7FFFFFFF && C * krs <= 0x7FFFFFFF) {
     const int64_t per_phase = (W + stride - 1) / stride;
     const unsigned bs = per_phase <= 64 ? 64u : per_phase <= 128 ? 128u : (unsigned)NT;  // few idle lanes per row
     const int64_t row_groups = ((H + stride - 1) / stride + kFewRows - 1) / kFewRows;   // per residue of y mod stride
     const dim3 grid((unsigned)((per_phase + bs - 1) / bs), (unsigned)(row_groups * stride * stride), (unsigned)N);
     const FewGeo fg{(int)stride, (int)pad, (int)R, (int)S, (int)g.OH, (int)g.OW, (int)K, (int)H, (int)W, (int)g.KB};
-    hipLaunchKernelGGL(variant == 1 ? pick_bp_few<true>((int)C) : pick_bp_few<false>((int)C), grid, dim3(bs), 0, s, gout, w,
+    hipLaunchKernelGGL(pack_w_few, dim3(blocks_for(C * krs)), dim3(NT), 0, s, w, Wm, g);
+    hipLaunchKernelGGL(variant == 1 ? pick_bp_few<true>((int)C) : pick_bp_few<false>((int)C), grid, dim3(bs), 0, s, gout, Wm,
                        gin, fg);
     CHECK_LAUNCH(who);
     return FPEMU_OK;

@@ -64,7 +64,10 @@ def test_conv_vs_reference_fixture(hip, bname, variant, fused):
                                   (2, 192, 7, 7, 128, 3, 3, 1, 1), (33, 128, 56, 56, 128, 3, 3, 1, 1),
                                   # few input channels: the direct backward-data kernel (phases of the stride)
                                   (2, 4, 17, 19, 128, 3, 3, 1, 1), (3, 2, 20, 23, 16, 5, 5, 3, 2),
-                                  (1, 3, 64, 300, 64, 7, 7, 2, 3)])
+                                  (1, 3, 64, 300, 64, 7, 7, 2, 3),
+                                  # ... its channel batches of 8: an odd count, a tail, one batch and a tail
+                                  (2, 3, 13, 17, 24, 3, 3, 2, 1), (1, 2, 11, 9, 20, 4, 4, 2, 1),
+                                  (2, 1, 9, 9, 12, 3, 3, 1, 1)])
 def test_conv_vs_oracle(hip, bname, variant, fused, case):
     """Batches with C or K < 64 included: every image is convolved (the reference collapses them)."""
     N, C, H, W, K, R, S, st, pd = case
