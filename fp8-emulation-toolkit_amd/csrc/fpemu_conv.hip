@@ -33,6 +33,11 @@
 #include "../../include/fpemu_hip.h"
 
 extern "C" void fpemu_set_error_(const char *msg);
+extern "C" int fpemu_gemm_chain_start_launch_(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                                              int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans,
+                                              int variant, int64_t batch, int64_t stride_a, int64_t stride_b,
+                                              int64_t stride_c, int64_t k_segments, int64_t kseg_stride_a,
+                                              int64_t kseg_stride_b, int start, const float *init, void *stream);
 
 namespace {
 
@@ -396,17 +401,8 @@ template <bool FUSED> bp_few_fn pick_bp_few(int C) {
        : C == 3 ? bp_few_channels<FUSED, 3> : bp_few_channels<FUSED, 4>;
 }
 
-// out[n][k][p] = bias[k] (+0 when channel padding exists in the reference: turns a -0 bias into +0), or 0
-__global__ __launch_bounds__(NT) void fill_rows(float *__restrict__ out, const float *__restrict__ bias,
-                                                int64_t rows_per_img, int64_t P, int64_t total, int add_zero) {
-  for (int64_t i = gtid(); i < total; i += gstride()) {
-    float b = 0.f;
-    if (bias != nullptr) {
-      b = bias[(i / P) % rows_per_img];
-      if (add_zero) b = b + 0.0f;
-    }
-    out[i] = b;
-  }
+__global__ __launch_bounds__(NT) void fill_zero(float *__restrict__ out, int64_t total) {
+  for (int64_t i = gtid(); i < total; i += gstride()) out[i] = 0.f;
 }
 
 // grid for the gather kernels: x over the pixels of a row, y over (image, kk) rows
@@ -581,16 +577,15 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   hipLaunchKernelGGL(pack_w_fp, dim3(blocks_for(K * crs)), dim3(NT), 0, s, w, Wm, g);
   CHECK_LAUNCH(who);
-  hipLaunchKernelGGL(fill_rows, dim3(blocks_for(N * K * P)), dim3(NT), 0, s, out, bias, K, P, N * K * P,
-                     (int)(C % 64 != 0));
-  CHECK_LAUNCH(who);
+  // the chains start at bias[k] (+0 when channel padding exists in the reference: turns a -0 bias into +0), or at +0
+  const int start = bias == nullptr ? 3 : C % 64 != 0 ? 2 : 1;
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
     hipLaunchKernelGGL((P % 4 == 0 && ((uintptr_t)cols % 16u) == 0) ? cols_fp<true> : cols_fp<false>, gather_grid(P, nb * crs),
                        dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs);
     CHECK_LAUNCH(who);
-    rc = fpemu_gemm_chain_f32(out + n0 * K * P, Wm, cols, K, P, crs, crs, P, P, 0, 0, variant, nb, 0, crs * P,
-                              K * P, 1, 0, 0, stream);
+    rc = fpemu_gemm_chain_start_launch_(out + n0 * K * P, Wm, cols, K, P, crs, crs, P, P, 0, 0, variant, nb, 0, crs * P,
+                                        K * P, 1, 0, 0, start, bias, stream);
     if (rc != FPEMU_OK) return rc;
   }
   return FPEMU_OK;
@@ -637,16 +632,13 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
   if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   hipLaunchKernelGGL(pack_w_bp, dim3(blocks_for(C * krs)), dim3(NT), 0, s, w, Wm, g);
   CHECK_LAUNCH(who);
-  hipLaunchKernelGGL(fill_rows, dim3(blocks_for(N * C * HW)), dim3(NT), 0, s, gin, (const float *)nullptr, C, HW,
-                     N * C * HW, 0);
-  CHECK_LAUNCH(who);
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
     hipLaunchKernelGGL((HW % 4 == 0 && ((uintptr_t)cols % 16u) == 0) ? cols_bp<true> : cols_bp<false>, gather_grid(HW, nb * krs),
                        dim3(NT), 0, s, gout + n0 * K * P, cols, g, nb * krs);
     CHECK_LAUNCH(who);
-    rc = fpemu_gemm_chain_f32(gin + n0 * C * HW, Wm, cols, C, HW, krs, krs, HW, HW, 0, 0, variant, nb, 0, krs * HW,
-                              C * HW, 1, 0, 0, stream);
+    rc = fpemu_gemm_chain_start_launch_(gin + n0 * C * HW, Wm, cols, C, HW, krs, krs, HW, HW, 0, 0, variant, nb, 0,
+                                        krs * HW, C * HW, 1, 0, 0, 3, nullptr, stream);   // chains start at +0
     if (rc != FPEMU_OK) return rc;
   }
   return FPEMU_OK;
@@ -668,17 +660,19 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
   hipStream_t s = (hipStream_t)stream;
   float *Gm = (float *)ws, *cols = Gm + wf;
   const int64_t P = g.OH * g.OW, crs = C * R * S;
-  hipLaunchKernelGGL(fill_rows, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, (const float *)nullptr, K, crs,
-                     K * crs, 0);
-  CHECK_LAUNCH(who);
+  if (N == 0) {  // no image: the gradient is +0
+    hipLaunchKernelGGL(fill_zero, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, K * crs);
+    CHECK_LAUNCH(who);
+  }
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
     hipLaunchKernelGGL((P % 4 == 0 && ((uintptr_t)cols % 16u) == 0) ? cols_fp<true> : cols_fp<false>, gather_grid(P, nb * crs),
                        dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs);
     CHECK_LAUNCH(who);
     // one chain across the chunk's images in ONE launch: k segments = images (chunks follow in order)
-    rc = fpemu_gemm_chain_f32(Gm, gout + n0 * K * P, cols, K, crs, P, P, P, crs, 0, 1, variant, 1, 0, 0, 0, nb,
-                              K * P, crs * P, stream);
+    // (the first chunk's chains start at +0, the later ones where the chunk before left them)
+    rc = fpemu_gemm_chain_start_launch_(Gm, gout + n0 * K * P, cols, K, crs, P, P, P, crs, 0, 1, variant, 1, 0, 0, 0, nb,
+                                        K * P, crs * P, n0 == 0 ? 3 : 0, nullptr, stream);
     if (rc != FPEMU_OK) return rc;
   }
   hipLaunchKernelGGL(unpack_gw, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, gw, g);

@@ -204,7 +204,18 @@ struct Batch {
   int64_t sa, sb, sc;
   int64_t ka, kb;
   int nseg;
+  // CHAIN mode, where the chains start: 0 = at C's current values, 1 = at init[row], 2 = at init[row] + 0.0f (a -0
+  // becomes +0), 3 = at +0.  (1-3: C is written only -- the convolution's bias / zero fill and its read-back are gone)
+  int start;
+  const float *init;
 };
+
+__device__ __forceinline__ float chain_start(const Batch &bt, const float *C, int64_t idx, int row) {
+  if (bt.start == 0) return C[idx];
+  if (bt.start == 3) return 0.f;
+  const float b = bt.init[row];
+  return bt.start == 2 ? b + 0.0f : b;
+}
 
 // CHAIN = false: acc starts at +0 and C = C + (alpha*acc + beta*C)      (simple_gemm, impl.cpp:226-231)
 // CHAIN = true : acc starts at C's current value and C = acc             (the conv kernels: MMEngine loads
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
       float v = 0.f;
       if constexpr (CHAIN) {
         const int r = m0 + (i >> 2) * 64 + ty * 4 + (i & 3), c = n0 + (j >> 2) * 64 + tx * 4 + (j & 3);
-        if (r < A.R && c < B.R) v = C[(int64_t)r * ldc + c];
+        if (r < A.R && c < B.R) v = chain_start(bt, C, (int64_t)r * ldc + c, r);
       }
       acc2[i][j >> 1][j & 1] = v;
     }
@@ -396,7 +407,7 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
         } else if constexpr (CHAIN) {
           const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int col = n0 + wn + j * 32 + li;
-          if (row < A.R && col < B.R) acc[i][j][r] = C[(int64_t)row * ldc + col];
+          if (row < A.R && col < B.R) acc[i][j][r] = chain_start(bt, C, (int64_t)row * ldc + col, row);
         }
       }
 
@@ -846,7 +857,7 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = m0 + wm + 4 * lk + r;
-      if (row < M && col < N) acc[r] = C[(int64_t)row * ldc + col];
+      if (row < M && col < N) acc[r] = chain_start(bt, C, (int64_t)row * ldc + col, row);
     }
   }
   // this workgroup's rows / columns are whole tiles of vector-aligned operands: only k can be ragged
@@ -1209,7 +1220,7 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = m0 + wm + 4 * lk + r;
-      if (row < M && col < N) acc[r] = C[(int64_t)row * ldc + col];
+      if (row < M && col < N) acc[r] = chain_start(bt, C, (int64_t)row * ldc + col, row);
     }
   }
   __syncthreads();  // tile 0 is in LDS buffer 0
@@ -1442,5 +1453,21 @@ extern "C" int fpemu_gemm_chain_f32(float *C, const float *A, const float *B, in
   }
   return launch_gemm("fpemu_gemm_chain_f32", C, A, B, M, N, K, lda, ldb, ldc, 1.0f, a_trans, b_trans, variant,
                      true, batch, Batch{stride_a, stride_b, stride_c, kseg_stride_a, kseg_stride_b, (int)k_segments},
+                     stream);
+}
+
+// fpemu_gemm_chain_f32 with the chains' starting values given instead of read from C (library-internal, used by
+// fpemu_conv.hip's gathered forms): start 1 = init[row], 2 = init[row] + 0.0f, 3 = +0 (init unused).  C is only written.
+extern "C" int fpemu_gemm_chain_start_launch_(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                                              int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans,
+                                              int variant, int64_t batch, int64_t stride_a, int64_t stride_b,
+                                              int64_t stride_c, int64_t k_segments, int64_t kseg_stride_a,
+                                              int64_t kseg_stride_b, int start, const float *init, void *stream) {
+  if (k_segments < 1 || k_segments > 0x7FFFFFFF || start < 0 || start > 3 || ((start == 1 || start == 2) && !init)) {
+    fpemu_set_error_("fpemu_gemm_chain_start_launch_: bad k_segments / start");
+    return FPEMU_EINVAL;
+  }
+  return launch_gemm("fpemu_gemm_chain_f32", C, A, B, M, N, K, lda, ldb, ldc, 1.0f, a_trans, b_trans, variant, true, batch,
+                     Batch{stride_a, stride_b, stride_c, kseg_stride_a, kseg_stride_b, (int)k_segments, start, init},
                      stream);
 }
