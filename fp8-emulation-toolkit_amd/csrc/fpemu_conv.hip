@@ -46,18 +46,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Geo {
   int64_t N, C, H, W, K, R, S, stride, pad, OH, OW, CB, KB;
+  int64_t KP;  // forward, gathered form: the chain length C*R*S padded to whole k tiles of the GEMM (-0 weights times
+               // +0 rows of cols: products of -0, which change no sum).  Only C < 64 leaves a ragged k tile.
 };
 
 __device__ __forceinline__ int64_t gtid() { return (int64_t)blockIdx.x * NT + threadIdx.x; }
 __device__ __forceinline__ int64_t gstride() { return (int64_t)gridDim.x * NT; }
 
-// Wfp[k][(cb, kj, ki, c2)] = w[k][cb*CB + c2][kj][ki]      (first / step: this thread's share of a launch)
+// Wfp[k][(cb, kj, ki, c2)] = w[k][cb*CB + c2][kj][ki], rows of KP floats (zeros behind the C*R*S weights)
+// (first / step: this thread's share of a launch)
 __device__ __forceinline__ void pack_w_fp_body(const float *__restrict__ w, float *__restrict__ Wm, const Geo &g,
                                                int64_t first, int64_t step) {
-  const int64_t crs = g.C * g.R * g.S, total = g.K * crs;
+  const int64_t crs = g.C * g.R * g.S, total = g.K * g.KP;
   for (int64_t i = first; i < total; i += step) {
-    const int64_t k = i / crs;
-    int64_t kk = i % crs;
+    const int64_t k = i / g.KP;
+    int64_t kk = i % g.KP;
+    if (kk >= crs) { Wm[i] = -0.0f; continue; }   // times the zero rows of cols: -0, which leaves any sum as it is
     const int64_t c2 = kk % g.CB; kk /= g.CB;
     const int64_t ki = kk % g.S; kk /= g.S;
     const int64_t kj = kk % g.R;
@@ -104,14 +108,23 @@ __global__ __launch_bounds__(NT) void pack_w_bp(const float *__restrict__ w, flo
 // cols[n][(cb, kj, ki, c2)][(oj, oi)] = x[n0 + n][cb*CB + c2][oj*s + kj - pad][oi*s + ki - pad], 0 outside.
 // One (image, kk) row of the gathered matrix per blockIdx.y (decoded once, scalar), threads along the
 // pixels: coalesced stores, row-local loads, 32-bit index arithmetic per element.
-template <bool vec4>
+// ST = 1 / 2: the stride, known at compile time -- a vector whose four pixels lie inside one image row takes them from
+// 4 / 7 contiguous floats (one / two wide 4-byte-aligned loads instead of four loads with a bounds test each).
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+template <bool vec4, int ST>
 __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float *__restrict__ cols, Geo g,
-                                              int64_t nrows) {
+                                              int64_t nrows, int rows_per_img) {
   const int P = (int)(g.OH * g.OW), OW = (int)g.OW, H = (int)g.H, W = (int)g.W, st = (int)g.stride;
   const int crs = (int)(g.C * g.R * g.S);
   for (int64_t row = blockIdx.y; row < nrows; row += gridDim.y) {
-    int kk = (int)(row % crs);
-    const int64_t n = row / crs;
+    int kk = (int)(row % rows_per_img);
+    const int64_t n = row / rows_per_img;
+    if (kk >= crs) {  // the zero rows that pad the chain to whole k tiles (forward: rows_per_img = KP)
+      float *z = cols + row * P;
+      for (int p = blockIdx.x * NT + threadIdx.x; p < P; p += gridDim.x * NT) z[p] = 0.f;
+      continue;
+    }
     const int c2 = kk % (int)g.CB; kk /= (int)g.CB;
     const int ki = kk % (int)g.S; kk /= (int)g.S;
     const int kj = kk % (int)g.R;
@@ -123,6 +136,22 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
       for (int p = (blockIdx.x * NT + threadIdx.x) * 4; p < P; p += gridDim.x * NT * 4) {
         f32x4 o;
         int oj = p / OW, oi = p - oj * OW;
+        if constexpr (ST == 1 || ST == 2) {
+          const int y = oj * ST + y0, xf = oi * ST + x0;
+          if (oi + 3 < OW && (unsigned)y < (unsigned)H && xf >= 0 && xf + 3 * ST < W) {
+            const float *q = src + y * W + xf;
+            if constexpr (ST == 1) {
+              const f32x4u a = *reinterpret_cast<const f32x4u *>(q);
+              o = f32x4{a[0], a[1], a[2], a[3]};
+            } else {
+              const f32x4u a = *reinterpret_cast<const f32x4u *>(q);
+              const f32x3u b = *reinterpret_cast<const f32x3u *>(q + 4);
+              o = f32x4{a[0], a[2], b[0], b[2]};
+            }
+            *reinterpret_cast<f32x4 *>(dst + p) = o;
+            continue;
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int y = oj * st + y0, xx = oi * st + x0;
@@ -141,6 +170,12 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
       dst[p] = v;
     }
   }
+}
+
+typedef void (*cols_fp_fn)(const float *, float *, Geo, int64_t, int);
+cols_fp_fn pick_cols_fp(bool vec4, int64_t stride) {
+  if (!vec4) return cols_fp<false, 0>;
+  return stride == 1 ? cols_fp<true, 1> : stride == 2 ? cols_fp<true, 2> : cols_fp<true, 0>;
 }
 
 // colsb[n][(ob, tj, ti, o2)][(ih, iw)] = gout[n][ob*KB + o2][oj][oi] with kj = R-1-tj, ki = ti,
@@ -442,6 +477,7 @@ int make_geo(const char *who, Geo &g, int64_t N, int64_t C, int64_t H, int64_t W
   g.OW = (W + 2 * pad - S) / stride + 1;
   g.CB = C < 64 ? C : 64;
   g.KB = K < 64 ? K : 64;
+  g.KP = (C * R * S + 31) / 32 * 32;
   if (C * R * S > 0x7FFFFFFF || K * R * S > 0x7FFFFFFF || g.OH * g.OW > 0x7FFFFFFF || H * W > 0x7FFFFFFF)
     return fail(who, FPEMU_EINVAL, "dimension out of range");
   return FPEMU_OK;
@@ -454,6 +490,9 @@ void ws_layout(int kind, const Geo &g, int64_t &w_floats, int64_t &per_img) {
   if (kind == FPEMU_CONV_BP) {
     w_floats = g.C * g.K * g.R * g.S;
     per_img = g.K * g.R * g.S * g.H * g.W;
+  } else if (kind == FPEMU_CONV_FP) {
+    w_floats = g.K * g.KP;
+    per_img = g.KP * g.OH * g.OW;
   } else {
     w_floats = g.K * g.C * g.R * g.S;
     per_img = g.C * g.R * g.S * g.OH * g.OW;
@@ -568,23 +607,24 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   if ((int64_t)(ws_bytes / 4) < wf) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   hipStream_t s = (hipStream_t)stream;
   float *Wm = (float *)ws, *cols = Wm + wf;
-  const int64_t P = g.OH * g.OW, crs = C * R * S;
+  const int64_t P = g.OH * g.OW;
   if (FPEMU_CONV_IMPLICIT && variant == 1 && stride == 1 && C % 64 == 0 && K % 64 == 0) {
     rc = implicit_conv(who, out, in, Wm, bias, N, C, H, W, K, R, S, pad, pad, g.OH, g.OW, 0, cols,
                        (int64_t)(ws_bytes / 4) - wf, s, 1, PackJob{w, Wm, g});
     if (rc != 1) return rc;  // 1: workspace too small for the padded planes (nothing launched) -> the gathered form below
   }
   if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
-  hipLaunchKernelGGL(pack_w_fp, dim3(blocks_for(K * crs)), dim3(NT), 0, s, w, Wm, g);
+  const int64_t kp = g.KP;  // chain length with its zero tail
+  hipLaunchKernelGGL(pack_w_fp, dim3(blocks_for(K * kp)), dim3(NT), 0, s, w, Wm, g);
   CHECK_LAUNCH(who);
   // the chains start at bias[k] (+0 when channel padding exists in the reference: turns a -0 bias into +0), or at +0
   const int start = bias == nullptr ? 3 : C % 64 != 0 ? 2 : 1;
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL((P % 4 == 0 && ((uintptr_t)cols % 16u) == 0) ? cols_fp<true> : cols_fp<false>, gather_grid(P, nb * crs),
-                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs);
+    hipLaunchKernelGGL(pick_cols_fp(P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, stride), gather_grid(P, nb * kp),
+                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * kp, (int)kp);
     CHECK_LAUNCH(who);
-    rc = fpemu_gemm_chain_start_launch_(out + n0 * K * P, Wm, cols, K, P, crs, crs, P, P, 0, 0, variant, nb, 0, crs * P,
+    rc = fpemu_gemm_chain_start_launch_(out + n0 * K * P, Wm, cols, K, P, kp, kp, P, P, 0, 0, variant, nb, 0, kp * P,
                                         K * P, 1, 0, 0, start, bias, stream);
     if (rc != FPEMU_OK) return rc;
   }
@@ -666,8 +706,8 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
   }
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL((P % 4 == 0 && ((uintptr_t)cols % 16u) == 0) ? cols_fp<true> : cols_fp<false>, gather_grid(P, nb * crs),
-                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs);
+    hipLaunchKernelGGL(pick_cols_fp(P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, stride), gather_grid(P, nb * crs),
+                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs, (int)crs);
     CHECK_LAUNCH(who);
     // one chain across the chunk's images in ONE launch: k segments = images (chunks follow in order)
     // (the first chunk's chains start at +0, the later ones where the chunk before left them)

@@ -57,6 +57,10 @@ struct Operand {
   int64_t ld;   // leading dimension (elements) of the stored matrix
   int R, K;     // extents of op(X): R rows (M or N), K depth
   int vec;      // 16-byte loads allowed (alignment + extents checked on the host)
+  // What a load outside the matrix yields.  A tile's ragged k tail multiplies A's filler by B's: -0 for A and +0 for
+  // B make every such product -0, the one value that leaves ANY accumulator as it is (acc + -0 = acc; with +0 * +0 a
+  // chain sitting at -0 would turn +0).  Rows outside the matrix only feed results that are never stored.
+  float pad;
 };
 
 // Stage one TBK x ROWS tile (rows r0.., depth k0..) into registers: TBK*ROWS/1024 float4 per thread.
@@ -90,7 +94,7 @@ __device__ __forceinline__ void tile_load(const Operand &X, const float *base, i
       else v[h] = *reinterpret_cast<const f32x4 *>(src);
       continue;
     }
-    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    f32x4 t = {X.pad, X.pad, X.pad, X.pad};
     if constexpr (KCONT) {
       if (r < X.R) {
         const float *src = base + (int64_t)r * X.ld + k;
@@ -788,7 +792,7 @@ __device__ __forceinline__ f32x4 small_load_one(const Operand &X, const float *b
   k += k0;
   const float *src = KCONT ? base + (int64_t)r * X.ld + k : base + (int64_t)k * X.ld + r;
   if (FULL || whole) return *reinterpret_cast<const f32x4 *>(src);
-  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  f32x4 t = {X.pad, X.pad, X.pad, X.pad};
   const bool in_outer = KCONT ? (r < X.R) : (k < X.K);
   const int inner = KCONT ? k : r, inner_end = KCONT ? X.K : X.R;
   if (in_outer) {
@@ -1066,7 +1070,7 @@ __device__ __forceinline__ f32x4 ws_load_checked(const Operand &X, const float *
   r += r0;
   k += k0;
   const float *src = KCONT ? base + (int64_t)r * X.ld + k : base + (int64_t)k * X.ld + r;
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  f32x4 v = {X.pad, X.pad, X.pad, X.pad};
   const bool in_outer = KCONT ? (r < X.R) : (k < X.K);
   const int inner = KCONT ? k : r, inner_end = KCONT ? X.K : X.R;
   if (in_outer) {
@@ -1169,11 +1173,11 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
       cur.advance();
     };
     auto store = [&](int buf, const f32x4 (&xa)[LNV], const f32x4 (&xb)[LNV], unsigned out) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 za = {A.pad, A.pad, A.pad, A.pad}, zb = {B.pad, B.pad, B.pad, B.pad};
 #pragma unroll
       for (int h = 0; h < LNV; h++) {
-        ws_store_one<A_KCONT, TS>(As[buf], t, g + h * Geo::G, (MODE == 1 && ((out >> h) & 1u)) ? z : xa[h]);
-        ws_store_one<B_KCONT, TS>(Bs[buf], t, g + h * Geo::G, (MODE == 1 && ((out >> (8 + h)) & 1u)) ? z : xb[h]);
+        ws_store_one<A_KCONT, TS>(As[buf], t, g + h * Geo::G, (MODE == 1 && ((out >> h) & 1u)) ? za : xa[h]);
+        ws_store_one<B_KCONT, TS>(Bs[buf], t, g + h * Geo::G, (MODE == 1 && ((out >> (8 + h)) & 1u)) ? zb : xb[h]);
       }
     };
     static_for<WSD>([&](auto s_c) {  // tiles 0 .. WSD-1
@@ -1349,6 +1353,8 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   a.p = A; a.ld = lda; a.R = (int)M; a.K = (int)K;
   b.p = B; b.ld = ldb; b.R = (int)N; b.K = (int)K;
   const bool a_kcont = !a_trans, b_kcont = b_trans != 0;
+  a.pad = -0.0f;
+  b.pad = 0.0f;
   a.vec = aligned16(A) && (lda % 4 == 0) && (bt.sa % 4 == 0) && ((a_kcont ? K : M) % 4 == 0);
   b.vec = aligned16(B) && (ldb % 4 == 0) && (bt.sb % 4 == 0) && ((b_kcont ? K : N) % 4 == 0);
   const int c_vec = aligned16(C) && (ldc % 4 == 0) && (bt.sc % 4 == 0) && (N % 4 == 0);
@@ -1423,8 +1429,8 @@ extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float 
   const int tb = fpemu_gemm_conv_tile_(M, nvalid, batch);
   const int tiles_m = (int)(M / tb), tiles_n = (int)((nvalid + tb - 1) / tb);
   Operand a, b;
-  a.p = Wm; a.ld = crs; a.R = (int)M; a.K = 64; a.vec = 1;
-  b.p = reverse ? xp + (S - 1) : xp; b.ld = plane; b.R = tiles_n * tb; b.K = 64; b.vec = 1;
+  a.p = Wm; a.ld = crs; a.R = (int)M; a.K = 64; a.vec = 1; a.pad = -0.0f;
+  b.p = reverse ? xp + (S - 1) : xp; b.ld = plane; b.R = tiles_n * tb; b.K = 64; b.vec = 1; b.pad = 0.0f;
   Batch bt{0, cblocks * 64 * plane, M * OH * OW, 64, 64 * plane, (int)(cblocks * R * S)};
   ConvMap cm{bias, (int)S, (int)R, (int)Wp, reverse ? -1 : 1, (int)OW, (int)(OH * OW), (int)nvalid};
   const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)batch);

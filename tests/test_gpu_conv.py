@@ -86,6 +86,23 @@ def test_conv_vs_oracle(hip, bname, variant, fused, case):
     assert_bits_equal(y0, orc.conv2d_fp(x, w, None, st, pd, fused), "no bias")
 
 
+@pytest.mark.parametrize("bname,variant,fused", VARIANTS)
+@pytest.mark.parametrize("case", [(2, 3, 9, 9, 8, 3, 3, 2, 1), (1, 64, 8, 8, 64, 3, 3, 2, 1), (1, 64, 6, 6, 64, 3, 3, 1, 1)])
+def test_conv_fp_signed_zero_chains(hip, bname, variant, fused, case):
+    """Chains made of -0 products only: a -0 bias survives them where the reference has no channel padding (C a
+    multiple of 64) and is +0 where it has (C < 64: also the case whose chains get a zero tail up to a whole k tile)."""
+    N, C, H, W, K, R, S, st, pd = case
+    x = np.zeros((N, C, H, W), np.float32)
+    w = -np.ones((K, C, R, S), np.float32)
+    b = np.zeros(K, np.float32)
+    b[::2] = -0.0
+    go = np.zeros((N, K, (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1), np.float32)
+    y, _, _ = _run_all(hip, x, w, b, go, st, pd, variant)
+    want = orc.conv2d_fp(x, w, b, st, pd, fused)
+    assert_bits_equal(y, want, "%s %s" % (bname, case))
+    assert (np.signbit(want).any()) == (C % 64 == 0)
+
+
 def test_implicit_conv_small_workspace_chunks_and_fallback(hip):
     """The implicit path with a workspace that holds the padded planes of two images only (chunked), and with one
     too small for any padded image but big enough for the gathered form of one image... which is larger, so: the

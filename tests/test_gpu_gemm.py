@@ -163,6 +163,33 @@ def test_gemm_chain_k_segments_and_batch(hip, variant, fused):
                                   1, 0, 0, 0, 0, 0, 0, None) == -1   # k_segments < 1
 
 
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(16, 16, 64), (64, 16, 576), (256, 256, 64), (512, 512, 64), (1024, 1024, 64),
+                                   (2048, 2048, 48), (48, 20, 130), (61, 99, 7)])
+def test_chain_signed_zeros(hip, variant, M, N, K):
+    """A chain sitting at -0 stays there through products of -0 and leaves it at the first +0 product, in every kernel
+    (tile sizes by problem size) and with a ragged last k tile: the tile's filler products are -0, not +0."""
+    L = hip.lib()
+    rng = np.random.default_rng(M + N + K)
+    A = -np.abs(rng.standard_normal((M, K))).astype(np.float32)      # negative
+    B = np.zeros((K, N), np.float32)                                 # +0: every product -0
+    first_pos = rng.integers(0, K + 1, size=N)                       # column j: from row first_pos[j] on, B is -0
+    first_pos[::4] = K                                               # (every fourth column: never)
+    for j in range(N):
+        B[first_pos[j]:, j] = -0.0                                   # ... and those products +0
+    C0 = np.full((M, N), -0.0, np.float32)
+    C0[::3, ::5] = 0.0
+    tA, tB, tC = _t(A), _t(B), _t(C0)
+    rc = L.fpemu_gemm_chain_f32(tC.data_ptr(), tA.data_ptr(), tB.data_ptr(), M, N, K, K, N, N, 0, 0, variant, 1, 0, 0, 0,
+                                1, 0, 0, None)
+    assert rc == 0, L.fpemu_last_error()
+    got = tC.cpu().numpy()
+    want_neg = np.signbit(C0) & (first_pos == K)[None, :]             # -0 start and no +0 product in the column
+    assert np.all(got == 0.0)
+    assert np.array_equal(np.signbit(got), want_neg), "%d sign bits differ" % int((np.signbit(got) != want_neg).sum())
+    assert want_neg.any() and not want_neg.all()
+
+
 @pytest.mark.parametrize("M,N,K,nseg,nb", [
     (64, 96, 128, 3, 2),      # 16 x 16 tiles, whole tiles of aligned operands (unchecked loads)
     (60, 100, 132, 3, 2),     # 16 x 16 tiles, aligned operands with ragged edges in M, N and k (masked loads)
