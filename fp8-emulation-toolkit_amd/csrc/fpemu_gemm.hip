@@ -39,7 +39,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // (the implicit-convolution operand: rows of the padded image shifted by the filter tap)
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-constexpr int BM = 128, BN = 128, BK = 16;  // VALU kernel: 128 x 128 x 16 tiles
+constexpr int BK = 16;  // VALU kernel: 128 x 128 x 16 tiles (64 x 64 x 16 for small problems)
+#ifndef FPEMU_SEQK_T64_BELOW
+#define FPEMU_SEQK_T64_BELOW 1024  // fewer 128 x 128 tiles than this (per launch): 64 x 64 tiles.  Measured, fraction of the
+                                   // 78.6 TFLOP/s VALU peak with 128 / 64 tiles: 768x768x4096 0.077 / 0.205, 2048^3 0.54 / 0.61,
+                                   // 3072x3072x2048 (576 tiles) 0.55 / 0.65, 4096^3 (1024 tiles) 0.72 / 0.67
+#endif
 #ifndef FPEMU_GEMM_MBK
 #define FPEMU_GEMM_MBK 32
 #endif
@@ -224,27 +229,31 @@ __device__ __forceinline__ float chain_start(const Batch &bt, const float *C, in
 // CHAIN = false: acc starts at +0 and C = C + (alpha*acc + beta*C)      (simple_gemm, impl.cpp:226-231)
 // CHAIN = true : acc starts at C's current value and C = acc             (the conv kernels: MMEngine loads
 //                C, continues the chain and stores it back, simple_mm_engine.cpp:18-24)
-template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL>
+// T = tile edge: 128 (a lane owns 8 x 8 results: two 4-row and two 4-column groups 64 apart), or 64 (4 x 4) for problems
+// with fewer 128 x 128 tiles than CUs -- a chain cannot be split along k, so only smaller tiles spread them.
+template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL, int T>
 __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, float *C, int64_t ldc,
                                                        int c_vec, float alpha, float beta,
                                                        int tiles_m, int tiles_n, Batch bt) {
+  static_assert(T == 128 || T == 64, "tile edge");
+  constexpr int H = T / 64;  // 4-row / 4-column groups per lane and dimension
   A.p += (int64_t)blockIdx.y * bt.sa;
   B.p += (int64_t)blockIdx.y * bt.sb;
   C += (int64_t)blockIdx.y * bt.sc;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * ldt<BM>()];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * ldt<BN>()];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * ldt<T>()];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * ldt<T>()];
   const int tid = threadIdx.x;
   int tm, tn;
   tile_of_block(tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * T, n0 = tn * T;
   const int ty = tid >> 4, tx = tid & 15;  // lane owns rows {ty*4.., 64+ty*4..} x cols {tx*4.., 64+tx*4..}
   const int K = A.K;
 
-  f32x2 acc2[8][4];  // acc2[i][j] = outputs (i, 2j) and (i, 2j+1)
+  f32x2 acc2[4 * H][2 * H];  // acc2[i][j] = outputs (i, 2j) and (i, 2j+1)
 #pragma unroll
-  for (int i = 0; i < 8; i++)
+  for (int i = 0; i < 4 * H; i++)
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < 4 * H; j++) {
       float v = 0.f;
       if constexpr (CHAIN) {
         const int r = m0 + (i >> 2) * 64 + ty * 4 + (i & 3), c = n0 + (j >> 2) * 64 + tx * 4 + (j & 3);
@@ -253,13 +262,13 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
       acc2[i][j >> 1][j & 1] = v;
     }
 
-  constexpr int LDT = ldt<BM>();
-  f32x4 pa[2], pb[2];
+  constexpr int LDT = ldt<T>();
+  f32x4 pa[BK * T / 1024], pb[BK * T / 1024];
   const float *abase = A.p, *bbase = B.p;
-  tile_load<A_KCONT, FULL, BK, BM>(A, abase, m0, 0, tid, pa);
-  tile_load<B_KCONT, FULL, BK, BN>(B, bbase, n0, 0, tid, pb);
-  tile_store<A_KCONT, BK, BM>(As[0], tid, pa);
-  tile_store<B_KCONT, BK, BN>(Bs[0], tid, pb);
+  tile_load<A_KCONT, FULL, BK, T>(A, abase, m0, 0, tid, pa);
+  tile_load<B_KCONT, FULL, BK, T>(B, bbase, n0, 0, tid, pb);
+  tile_store<A_KCONT, BK, T>(As[0], tid, pa);
+  tile_store<B_KCONT, BK, T>(Bs[0], tid, pb);
   __syncthreads();
 
   int cur = 0;
@@ -274,34 +283,39 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
         abase += bt.ka;
         bbase += bt.kb;
       }
-      tile_load<A_KCONT, FULL, BK, BM>(A, abase, m0, nk0, tid, pa);
-      tile_load<B_KCONT, FULL, BK, BN>(B, bbase, n0, nk0, tid, pb);
+      tile_load<A_KCONT, FULL, BK, T>(A, abase, m0, nk0, tid, pa);
+      tile_load<B_KCONT, FULL, BK, T>(B, bbase, n0, nk0, tid, pb);
     }
     const float *as = As[cur], *bs = Bs[cur];
 #pragma unroll 2
     for (int kk = 0; kk < BK; kk++) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&as[kk * LDT + ty * 4]);
-      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&as[kk * LDT + 64 + ty * 4]);
-      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(&bs[kk * LDT + tx * 4]);
-      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(&bs[kk * LDT + 64 + tx * 4]);
-      const float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      const f32x2 b2[4] = {{b0[0], b0[1]}, {b0[2], b0[3]}, {b1[0], b1[1]}, {b1[2], b1[3]}};
+      float a[4 * H];
+      f32x2 b2[2 * H];
+#pragma unroll
+      for (int h = 0; h < H; h++) {
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(&as[kk * LDT + h * 64 + ty * 4]);
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(&bs[kk * LDT + h * 64 + tx * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; e++) a[4 * h + e] = av[e];
+        b2[2 * h] = f32x2{bv[0], bv[1]};
+        b2[2 * h + 1] = f32x2{bv[2], bv[3]};
+      }
       // explicit 2-wide form so that every multiply and every add is a packed instruction
       // (v_pk_mul_f32 / v_pk_add_f32: two lanes of the chain per issue slot; left to the SLP
       // vectoriser half of the adds stayed scalar)
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
+      for (int i = 0; i < 4 * H; i++) {
         const f32x2 ai = {a[i], a[i]};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 2 * H; j++) {
           const f32x2 p = ai * b2[j];      // rounded products: values of their own (contraction is off)
           acc2[i][j] = acc2[i][j] + p;     // k ascending, one add per step
         }
       }
     }
     if (more) {
-      tile_store<A_KCONT, BK, BM>(As[cur ^ 1], tid, pa);
-      tile_store<B_KCONT, BK, BN>(Bs[cur ^ 1], tid, pb);
+      tile_store<A_KCONT, BK, T>(As[cur ^ 1], tid, pa);
+      tile_store<B_KCONT, BK, T>(Bs[cur ^ 1], tid, pb);
     }
     __syncthreads();
     cur ^= 1;
@@ -309,13 +323,13 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 
   const int M = A.R, N = B.R;
 #pragma unroll
-  for (int ih = 0; ih < 2; ih++)
+  for (int ih = 0; ih < H; ih++)
 #pragma unroll
     for (int ii = 0; ii < 4; ii++) {
       const int r = m0 + ih * 64 + ty * 4 + ii;
       if (r >= M) continue;
 #pragma unroll
-      for (int jh = 0; jh < 2; jh++) {
+      for (int jh = 0; jh < H; jh++) {
         const int c = n0 + jh * 64 + tx * 4;
         float *dst = C + (int64_t)r * ldc + c;
         if constexpr (CHAIN) {
@@ -1319,9 +1333,9 @@ typedef void (*mfma_fn)(Operand, Operand, float *, int64_t, float, float, int, i
 
 bool aligned16(const void *p) { return ((uintptr_t)p % 16u) == 0; }
 
-template <bool CHAIN, bool FULL> seqk_fn pick_seqk(bool a_kcont, bool b_kcont) {
-  return a_kcont ? (b_kcont ? gemm_seqk_kernel<true, true, CHAIN, FULL> : gemm_seqk_kernel<true, false, CHAIN, FULL>)
-                 : (b_kcont ? gemm_seqk_kernel<false, true, CHAIN, FULL> : gemm_seqk_kernel<false, false, CHAIN, FULL>);
+template <bool CHAIN, bool FULL, int T> seqk_fn pick_seqk(bool a_kcont, bool b_kcont) {
+  return a_kcont ? (b_kcont ? gemm_seqk_kernel<true, true, CHAIN, FULL, T> : gemm_seqk_kernel<true, false, CHAIN, FULL, T>)
+                 : (b_kcont ? gemm_seqk_kernel<false, true, CHAIN, FULL, T> : gemm_seqk_kernel<false, false, CHAIN, FULL, T>);
 }
 template <bool CHAIN, bool FULL, int TW> mfma_fn pick_mfma(bool a_kcont, bool b_kcont) {
   return a_kcont ? (b_kcont ? gemm_mfma_kernel<true, true, CHAIN, FULL, TW> : gemm_mfma_kernel<true, false, CHAIN, FULL, TW>)
@@ -1371,7 +1385,9 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   // so few chains that even 32 x 32 tiles leave most CUs idle: 16 x 16 tiles, one chain per workgroup (a CU's load
   // rate, not the chain, bounds a 32 x 32 tile: see gemm_mfma16ws_kernel)
   const bool tiny = small && FPEMU_GEMM_WS && t32 < FPEMU_GEMM_WS_TINY;
-  const int tb = tiny ? 16 : small ? SB : (variant == 1 && (t128 < 512 || M <= 64 || N <= 64)) ? 64 : 128;
+  // (the VALU kernel: 64 x 64 tiles when 128 x 128 ones would leave CUs without a workgroup)
+  const int tb = tiny ? 16 : small ? SB : (variant == 1 && (t128 < 512 || M <= 64 || N <= 64)) ? 64
+               : (variant != 1 && t128 < FPEMU_SEQK_T64_BELOW) ? 64 : 128;
   const int tiles_m = (int)((M + tb - 1) / tb), tiles_n = (int)((N + tb - 1) / tb);
   const int64_t nwg = (int64_t)tiles_m * tiles_n;
   if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "too many tiles");
@@ -1381,8 +1397,13 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)nwg, (unsigned)batch);
   if (variant == 0) {
-    seqk_fn fn = chain ? (full ? pick_seqk<true, true>(a_kcont, b_kcont) : pick_seqk<true, false>(a_kcont, b_kcont))
-                       : (full ? pick_seqk<false, true>(a_kcont, b_kcont) : pick_seqk<false, false>(a_kcont, b_kcont));
+    seqk_fn fn;
+    if (tb == 64)
+      fn = chain ? (full ? pick_seqk<true, true, 64>(a_kcont, b_kcont) : pick_seqk<true, false, 64>(a_kcont, b_kcont))
+                 : (full ? pick_seqk<false, true, 64>(a_kcont, b_kcont) : pick_seqk<false, false, 64>(a_kcont, b_kcont));
+    else
+      fn = chain ? (full ? pick_seqk<true, true, 128>(a_kcont, b_kcont) : pick_seqk<true, false, 128>(a_kcont, b_kcont))
+                 : (full ? pick_seqk<false, true, 128>(a_kcont, b_kcont) : pick_seqk<false, false, 128>(a_kcont, b_kcont));
     hipLaunchKernelGGL(fn, grid, dim3(NT), 0, s, a, b, C, ldc, c_vec, alpha, beta, tiles_m, tiles_n, bt);
   } else if (small) {
     if (FPEMU_GEMM_WS) {

@@ -94,6 +94,25 @@ def test_gemm_2048_sampled(hip, bname, variant, fused):
     assert ((C.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
 
 
+@pytest.mark.parametrize("bname,variant,fused", VARIANTS)
+@pytest.mark.parametrize("at,bt", [(False, False), (True, True)])
+def test_gemm_many_ragged_tiles_sampled(hip, bname, variant, fused, at, bt):
+    """More than 1024 tiles of 128 x 128 with ragged edges in M, N and k: the large-tile kernels' bounds-checked path
+    (smaller problems take the 64 x 64 / 32 x 32 / 16 x 16 kernels).  Oracle on a sample of rows."""
+    M, N, K = 4100, 4090, 37
+    g = torch.Generator(device=DEV).manual_seed(11)
+    A = torch.randn((K, M) if at else (M, K), device=DEV, generator=g)
+    B = torch.randn((N, K) if bt else (K, N), device=DEV, generator=g)
+    C = torch.zeros(M, N, device=DEV)
+    hip.gemm_(C, A, B, 1.0, at, bt, variant)
+    rows = [0, 127, 128, 2049, 4095, 4096, 4099]
+    An = (A.t() if at else A)[rows].contiguous().cpu().numpy()
+    Bn = (B.t() if bt else B).contiguous().cpu().numpy()
+    assert_bits_equal(C[rows].cpu().numpy(), orc.gemm(An, Bn, 1.0, fused=fused), bname + " ragged rows")
+    ref = (A.t() if at else A).double() @ (B.t() if bt else B).double()
+    assert ((C.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
 def test_simple_module_api(hip):
     """mpemu.cmodel.simple.{mm, matmul, addmm} keep the reference's call surface (simple.py:30-86)."""
     from mpemu.cmodel import simple

@@ -12,7 +12,8 @@ hip._SO = os.environ.get("FPEMU_LIB") or hip._SO  # tuning aid: a library built 
 PEAK = {1: 157.3, 0: 78.6}
 
 
-ITERS = int(os.environ.get("GEMM_ITERS", "5"))   # short kernels: use 50+ so the clock ramp of the first launches washes out
+ITERS = int(os.environ.get("GEMM_ITERS", "0"))   # 0: as many launches as fill ~80 ms (the clock ramp of the first launches
+                                                 # after an idle GPU reads 10-15 % low on a 1 ms kernel timed over 5 launches)
 
 
 def run(M, N, K, at, bt, variant, iters=None):
@@ -20,10 +21,17 @@ def run(M, N, K, at, bt, variant, iters=None):
     A = torch.randn((K, M) if at else (M, K), device="cuda")
     B = torch.randn((N, K) if bt else (K, N), device="cuda")
     C = torch.zeros(M, N, device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    hip.gemm_(C, A, B, 1.0, at, bt, variant)
+    e0.record()
+    hip.gemm_(C, A, B, 1.0, at, bt, variant)
+    e1.record()
+    torch.cuda.synchronize()
+    if not iters:
+        iters = max(5, min(200, int(80.0 / max(e0.elapsed_time(e1), 1e-3)) + 1))
     for _ in range(1 + iters // 5):
         hip.gemm_(C, A, B, 1.0, at, bt, variant)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
         hip.gemm_(C, A, B, 1.0, at, bt, variant)
