@@ -1259,9 +1259,15 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
       fb[0][st] = Bs[0][boff[st] + st * STEP];
     }
   }
-  for (int it = 0; it < total; it++) {
-    const float *as = As[it & 1], *bs = Bs[it & 1];
-    const float *an = As[(it & 1) ^ 1], *bn = Bs[(it & 1) ^ 1];
+  // One tile from LDS buffer PAR.  PAR is a compile-time constant (the tile loop below runs two tiles per trip): every
+  // fragment address is then one of the 2 * Q per-lane words plus an immediate, and the stream holds no VALU
+  // instruction at all.  With the buffer picked at run time the compiler rebuilt 32 addresses per tile with v_or_b32 --
+  // into registers the MFMA issued just before was still reading (measured: 52 cycles per dependent step with idle
+  // loaders against 35 for the same stream without those).
+  auto tile = [&](auto par_c, [[maybe_unused]] int it) {
+    constexpr int PAR = decltype(par_c)::value;
+    const float *as = As[PAR], *bs = Bs[PAR];
+    const float *an = As[PAR ^ 1], *bn = Bs[PAR ^ 1];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int c = q & 1;
@@ -1291,7 +1297,13 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
         WS_STAMP(2, it);
       }
     }
+  };
+  int it = 0;
+  for (; it + 2 <= total; it += 2) {
+    tile(std::integral_constant<int, 0>{}, it);
+    tile(std::integral_constant<int, 1>{}, it + 1);
   }
+  if (it < total) tile(std::integral_constant<int, 0>{}, it);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = m0 + wm + 4 * lk + r;
