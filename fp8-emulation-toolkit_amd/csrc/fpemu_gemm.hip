@@ -1014,7 +1014,10 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
 // that miss to HBM (its outstanding-miss budget over ~1 us), which is 0.93 us per 32 KiB tile against the chain's
 // 0.43 us -- a quarter of the chains per CU halves the bytes per CU and tile.
 #ifndef FPEMU_ABLATE_WS
-#define FPEMU_ABLATE_WS 0  // timing experiments only: 1 loaders skip the global loads, 2 skip the LDS stores
+#define FPEMU_ABLATE_WS 0  // timing experiments only: 1 loaders skip the global loads, 2 skip the LDS stores, 4 chain waves skip the MFMAs
+#endif
+#ifndef FPEMU_WS_PRIO
+#define FPEMU_WS_PRIO 0
 #endif
 #ifndef FPEMU_GEMM_WS_DEPTH
 #define FPEMU_GEMM_WS_DEPTH 8     // register stages of the loader waves = tiles a load is issued ahead of its LDS store
@@ -1160,7 +1163,12 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
     // With a conditional fetch the compiler cannot count the loads in flight and waits for ALL of them (vmcnt(0))
     // before every LDS store -- the prefetch distance would be gone.
     [[maybe_unused]] unsigned outside[WSD];  // MODE 1: bit h: A's vector h lies past the segment's end; bit 8 + h: B's
-    auto fetch = [&](f32x4 (&xa)[LNV], f32x4 (&xb)[LNV], unsigned &out) {
+    // MODE 1: the stage's tile reaches past its segment's end (uniform).  Only such a tile -- the last of a segment --
+    // takes the masked loads and the selecting stores; both arms of either branch issue the same loads / stores, so the
+    // counts of operations in flight survive the join.  (The masks cost ~25 VALU instructions per vector, issued on the
+    // SIMD a chain wave shares: measured 21.8 ns per chain step with them in every tile, 15.9 without.)
+    [[maybe_unused]] bool ragged[WSD];
+    auto fetch = [&](f32x4 (&xa)[LNV], f32x4 (&xb)[LNV], unsigned &out, bool &rag) {
       if constexpr (MODE == 0) {
 #pragma unroll
         for (int h = 0; h < LNV; h++) {
@@ -1172,7 +1180,7 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
         const int64_t offb = (cur.b - B.p) + (B_KCONT ? (int64_t)cur.k0 : (int64_t)cur.k0 * B.ld);
 #pragma unroll
         for (int h = 0; h < LNV; h++) {
-          if constexpr (MODE == 2) {
+          if (MODE == 2 || cur.k0 + SK <= K) {
             xa[h] = *reinterpret_cast<const f32x4 *>(pa_[h] + offa);
             xb[h] = *reinterpret_cast<const f32x4 *>(pb_[h] + offb);
           } else {
@@ -1184,44 +1192,62 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
           }
         }
       }
+      if constexpr (MODE == 1) rag = !(cur.k0 + SK <= K);
       cur.advance();
     };
-    auto store = [&](int buf, const f32x4 (&xa)[LNV], const f32x4 (&xb)[LNV], unsigned out) {
+    auto store = [&](int buf, const f32x4 (&xa)[LNV], const f32x4 (&xb)[LNV], unsigned out, bool rag) {
       const f32x4 za = {A.pad, A.pad, A.pad, A.pad}, zb = {B.pad, B.pad, B.pad, B.pad};
+      if (MODE == 1 && rag) {
 #pragma unroll
-      for (int h = 0; h < LNV; h++) {
-        ws_store_one<A_KCONT, TS>(As[buf], t, g + h * Geo::G, (MODE == 1 && ((out >> h) & 1u)) ? za : xa[h]);
-        ws_store_one<B_KCONT, TS>(Bs[buf], t, g + h * Geo::G, (MODE == 1 && ((out >> (8 + h)) & 1u)) ? zb : xb[h]);
+        for (int h = 0; h < LNV; h++) {
+          ws_store_one<A_KCONT, TS>(As[buf], t, g + h * Geo::G, ((out >> h) & 1u) ? za : xa[h]);
+          ws_store_one<B_KCONT, TS>(Bs[buf], t, g + h * Geo::G, ((out >> (8 + h)) & 1u) ? zb : xb[h]);
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < LNV; h++) {
+          ws_store_one<A_KCONT, TS>(As[buf], t, g + h * Geo::G, xa[h]);
+          ws_store_one<B_KCONT, TS>(Bs[buf], t, g + h * Geo::G, xb[h]);
+        }
       }
     };
     static_for<WSD>([&](auto s_c) {  // tiles 0 .. WSD-1
-      fetch(ra[decltype(s_c)::value], rb[decltype(s_c)::value], outside[decltype(s_c)::value]);
+      fetch(ra[decltype(s_c)::value], rb[decltype(s_c)::value], outside[decltype(s_c)::value], ragged[decltype(s_c)::value]);
     });
-    store(0, ra[0], rb[0], outside[0]);
-    fetch(ra[0], rb[0], outside[0]);  // tile WSD
+    store(0, ra[0], rb[0], outside[0], ragged[0]);
+    fetch(ra[0], rb[0], outside[0], ragged[0]);  // tile WSD
     __syncthreads();      // (the chain waves' first barrier)
     // during the multiplication of tile `it`: tile it+1 into LDS buffer (it+1) % 2, tile it+1+WSD into the stage it frees
-    auto step = [&](auto s_c, int it) {
+    // STEADY: every tile of the trip is followed by another one, so the store and the fetch are unconditional.  That is
+    // what keeps the prefetch distance: with the `it + 1 < total` test around them in the steady state the compiler's
+    // count of loads in flight joins a path that skipped its fetches at every step, and it waited vmcnt(3) / (1) / (0)
+    // before each store -- for the loads issued one tile ago, whatever WSD (seen in the ISA; the loaders then paced the
+    // chain at one memory round trip per tile).
+    auto step = [&](auto s_c, auto steady_c, int it) {
       constexpr int S1 = (decltype(s_c)::value + 1) % WSD;
+      constexpr bool STEADY = decltype(steady_c)::value;
       WS_STAMP(4, it);
-      if (it + 1 < total) {
+      if (STEADY || it + 1 < total) {
 #if !(FPEMU_ABLATE_WS & 2)
-        store((it + 1) & 1, ra[S1], rb[S1], outside[S1]);
+        store((it + 1) & 1, ra[S1], rb[S1], outside[S1], ragged[S1]);
 #endif
         WS_STAMP(5, it);
 #if !(FPEMU_ABLATE_WS & 1)
-        fetch(ra[S1], rb[S1], outside[S1]);
+        fetch(ra[S1], rb[S1], outside[S1], ragged[S1]);
 #endif
       }
       WS_STAMP(6, it);
       __syncthreads();
       WS_STAMP(7, it);
     };
-    for (int it = 0; it < total; it += WSD) {
+    int it = 0;
+    for (; it + WSD < total; it += WSD)   // tiles it .. it + WSD - 1, each with a successor
+      static_for<WSD>([&](auto s_c) { step(s_c, std::true_type{}, it + decltype(s_c)::value); });
+    {  // the last 1 .. WSD tiles
       bool done = false;  // uniform
       static_for<WSD>([&](auto s_c) {
         if (done) return;
-        step(s_c, it + decltype(s_c)::value);
+        step(s_c, std::false_type{}, it + decltype(s_c)::value);
         done = it + decltype(s_c)::value + 1 >= total;
       });
     }
@@ -1229,6 +1255,9 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
   }
 
   // ---- chain waves ----
+#if FPEMU_WS_PRIO
+  __builtin_amdgcn_s_setprio(3);  // ahead of the loader wave that shares the SIMD
+#endif
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = TS == 32 ? (w >> 1) * 16 : 0, wn = TS == 32 ? (w & 1) * 16 : 0;
   const int li = lane & 15, lk = lane >> 4;
@@ -1273,7 +1302,9 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
       const int c = q & 1;
 #pragma unroll
       for (int st = 0; st < Q; st++) {
+#if !(FPEMU_ABLATE_WS & 4)
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][st], fb[c][st], acc, 0, 0, 0);
+#endif
         if (q + 1 < 4) {  // fragments of the next quarter
           fa[c ^ 1][st] = as[aoff[st] + ((q + 1) * Q + st) * STEP];
           fb[c ^ 1][st] = bs[boff[st] + ((q + 1) * Q + st) * STEP];

@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from mpemu.pytquant.hip import _binding as hip
 hip._SO = os.environ.get("FPEMU_LIB") or hip._SO
 L = hip.lib()
-for (K, crs, P, nimg) in ((64, 576, 3136, 32), (128, 1152, 784, 32), (256, 2304, 196, 32), (64, 147, 12544, 32)):
+SHAPES = ((64, 576, 3136, 32), (128, 1152, 784, 32), (256, 2304, 196, 32), (64, 147, 12544, 32))
+if os.environ.get('WU_SHAPES'):
+    SHAPES = tuple(tuple(int(v) for v in sh.split('x')) for sh in os.environ['WU_SHAPES'].split(','))
+for (K, crs, P, nimg) in SHAPES:
     go = torch.randn(nimg, K, P, device="cuda")
     cols = torch.randn(nimg, crs, P, device="cuda")
     G = torch.zeros(K, crs, device="cuda")
