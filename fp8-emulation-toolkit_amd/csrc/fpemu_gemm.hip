@@ -1354,6 +1354,9 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
 #ifndef FPEMU_GEMM_WS
 #define FPEMU_GEMM_WS 1
 #endif
+#ifndef FPEMU_GEMM_SMALL_MAX
+#define FPEMU_GEMM_SMALL_MAX 320    // up to this many 32 x 32 tiles (per launch): the small-tile chain kernels
+#endif
 #ifndef FPEMU_GEMM_WS_TINY
 #define FPEMU_GEMM_WS_TINY 128   // fewer 32 x 32 tiles than this (per launch): 16 x 16 tiles
 #endif
@@ -1423,7 +1426,7 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64) * batch;
   // fewer 64 x 64 tiles than CUs: the chains are latency-bound -> 32 x 32 tiles of 16x16x4 MFMAs (gemm_mfma16_kernel)
   const int64_t t32 = ((M + 31) / 32) * ((N + 31) / 32) * batch;
-  const bool small = variant == 1 && t64 < 256 && t32 <= 320;  // up to ~1.25 waves per SIMD (measured: at 576 tiles
+  const bool small = variant == 1 && t64 < 256 && t32 <= FPEMU_GEMM_SMALL_MAX;  // up to ~1.25 waves per SIMD (measured: at 576 tiles
                                                                // the 64 x 64 kernel is the faster one again)
   // so few chains that even 32 x 32 tiles leave most CUs idle: 16 x 16 tiles, one chain per workgroup (a CU's load
   // rate, not the chain, bounds a 32 x 32 tile: see gemm_mfma16ws_kernel)
