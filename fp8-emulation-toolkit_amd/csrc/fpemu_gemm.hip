@@ -1016,6 +1016,9 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
 #ifndef FPEMU_ABLATE_WS
 #define FPEMU_ABLATE_WS 0  // timing experiments only: 1 loaders skip the global loads, 2 skip the LDS stores, 4 chain waves skip the MFMAs
 #endif
+#ifndef FPEMU_WS_SPREAD
+#define FPEMU_WS_SPREAD 1
+#endif
 #ifndef FPEMU_WS_PRIO
 #define FPEMU_WS_PRIO 0
 #endif
@@ -1046,7 +1049,11 @@ template <int TS> struct WsGeo {
   static constexpr int G = NL / 256;
   static constexpr int NPASS = TS * SK / 1024;
   static constexpr int LNV = NPASS / G;       // vectors per operand, tile and loader thread (2 for both sizes)
-  static constexpr int NTHREADS = NC * 64 + NL;
+  // 16 x 16: eight waves are launched and waves 4, 6 and 7 leave at once, so that (waves going to the SIMDs in turn)
+  // the chain wave has SIMD 0 to itself and the loaders -- waves 1, 2, 3 and 5 -- sit on SIMDs 1, 2, 3 and 1: a loader
+  // wave on the chain's SIMD takes issue slots between its dependent MFMAs.
+  static constexpr bool SPREAD = TS == 16 && FPEMU_WS_SPREAD;
+  static constexpr int NTHREADS = SPREAD ? 512 : NC * 64 + NL;
   static constexpr int WORDS = TS == 32 ? SK * 48 : SK * 16;  // one operand image
 };
 // thread t (0..255) of pass `pass` -> (row r, first k) of its vector: four consecutive k (KCONT) or four rows
@@ -1123,10 +1130,13 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
 
   // wave-uniform by construction; readfirstlane makes it a scalar branch, so each barrier below is executed by
   // exactly the waves of its role
-  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NCT) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+  if (Geo::SPREAD && (wave == 4 || wave >= 6)) return;   // before any barrier: a finished wave is not waited for
+  if (wave >= Geo::NC) {
     // ---- loader waves: tile j travels through register stage j % WSD and LDS buffer j % 2 ----
-    const int t = (threadIdx.x - NCT) & 255;   // position within a 256-thread pass of the tile
-    const int g = (threadIdx.x - NCT) >> 8;    // this wave's passes: g, g + G, ... (wave-uniform)
+    const int lt = Geo::SPREAD ? (((wave < 4 ? wave - 1 : 3) << 6) | (int)(threadIdx.x & 63)) : (int)threadIdx.x - NCT;
+    const int t = lt & 255;   // position within a 256-thread pass of the tile
+    const int g = lt >> 8;    // this wave's passes: g, g + G, ... (wave-uniform)
     if (total <= 0) {     // K = 0: nothing to load (the operands may be null); only the chain waves' first barrier
       __syncthreads();
       return;
