@@ -1367,6 +1367,10 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
 #ifndef FPEMU_GEMM_SMALL_MAX
 #define FPEMU_GEMM_SMALL_MAX 320    // up to this many 32 x 32 tiles (per launch): the small-tile chain kernels
 #endif
+#ifndef FPEMU_GEMM_WS_TINY16
+#define FPEMU_GEMM_WS_TINY16 256  // ... and at most one 16 x 16 tile per CU (measured 320x320x4096, 400 tiles: 34 ns a step
+                                  // in two rounds of 16 x 16 tiles against 22 as 100 tiles of 32 x 32)
+#endif
 #ifndef FPEMU_GEMM_WS_TINY
 #define FPEMU_GEMM_WS_TINY 128   // fewer 32 x 32 tiles than this (per launch): 16 x 16 tiles
 #endif
@@ -1440,7 +1444,8 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
                                                                // the 64 x 64 kernel is the faster one again)
   // so few chains that even 32 x 32 tiles leave most CUs idle: 16 x 16 tiles, one chain per workgroup (a CU's load
   // rate, not the chain, bounds a 32 x 32 tile: see gemm_mfma16ws_kernel)
-  const bool tiny = small && FPEMU_GEMM_WS && t32 < FPEMU_GEMM_WS_TINY;
+  const int64_t t16 = ((M + 15) / 16) * ((N + 15) / 16) * batch;
+  const bool tiny = small && FPEMU_GEMM_WS && t32 < FPEMU_GEMM_WS_TINY && t16 <= FPEMU_GEMM_WS_TINY16;
   // (the VALU kernel: 64 x 64 tiles when 128 x 128 ones would leave CUs without a workgroup)
   const int tb = tiny ? 16 : small ? SB : (variant == 1 && (t128 < 512 || M <= 64 || N <= 64)) ? 64
                : (variant != 1 && t128 < FPEMU_SEQK_T64_BELOW) ? 64 : 128;
