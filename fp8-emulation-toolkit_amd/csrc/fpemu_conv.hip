@@ -33,6 +33,7 @@
 #include "../../include/fpemu_hip.h"
 
 extern "C" void fpemu_set_error_(const char *msg);
+extern "C" int fpemu_gemm_tile_edge_(int64_t M, int64_t N, int64_t batch, int variant);
 extern "C" int fpemu_gemm_chain_start_launch_(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
                                               int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans,
                                               int variant, int64_t batch, int64_t stride_a, int64_t stride_b,
@@ -114,15 +115,16 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 template <bool vec4, int ST>
 __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float *__restrict__ cols, Geo g,
-                                              int64_t nrows, int rows_per_img) {
+                                              int64_t nrows, int rows_per_img, int pitch) {
+  // pitch: floats per gathered row, >= OH*OW (weight update: OH*OW padded to whole k tiles; the tail is +0)
   const int P = (int)(g.OH * g.OW), OW = (int)g.OW, H = (int)g.H, W = (int)g.W, st = (int)g.stride;
   const int crs = (int)(g.C * g.R * g.S);
   for (int64_t row = blockIdx.y; row < nrows; row += gridDim.y) {
     int kk = (int)(row % rows_per_img);
     const int64_t n = row / rows_per_img;
     if (kk >= crs) {  // the zero rows that pad the chain to whole k tiles (forward: rows_per_img = KP)
-      float *z = cols + row * P;
-      for (int p = blockIdx.x * NT + threadIdx.x; p < P; p += gridDim.x * NT) z[p] = 0.f;
+      float *z = cols + row * pitch;
+      for (int p = blockIdx.x * NT + threadIdx.x; p < pitch; p += gridDim.x * NT) z[p] = 0.f;
       continue;
     }
     const int c2 = kk % (int)g.CB; kk /= (int)g.CB;
@@ -130,7 +132,8 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
     const int kj = kk % (int)g.R;
     const int cb = kk / (int)g.R;
     const float *src = x + (n * g.C + cb * g.CB + c2) * (int64_t)H * W;
-    float *dst = cols + row * P;
+    float *dst = cols + row * pitch;
+    for (int p = P + blockIdx.x * NT + threadIdx.x; p < pitch; p += gridDim.x * NT) dst[p] = 0.f;
     const int y0 = kj - (int)g.pad, x0 = ki - (int)g.pad;
     if constexpr (vec4) {  // four pixels per lane, one 16-byte store (rows are whole vectors and 16-byte aligned)
       for (int p = (blockIdx.x * NT + threadIdx.x) * 4; p < P; p += gridDim.x * NT * 4) {
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
   }
 }
 
-typedef void (*cols_fp_fn)(const float *, float *, Geo, int64_t, int);
+typedef void (*cols_fp_fn)(const float *, float *, Geo, int64_t, int, int);
 cols_fp_fn pick_cols_fp(bool vec4, int64_t stride) {
   if (!vec4) return cols_fp<false, 0>;
   return stride == 1 ? cols_fp<true, 1> : stride == 2 ? cols_fp<true, 2> : cols_fp<true, 0>;
@@ -436,6 +439,17 @@ template <bool FUSED> bp_few_fn pick_bp_few(int C) {
        : C == 3 ? bp_few_channels<FUSED, 3> : bp_few_channels<FUSED, 4>;
 }
 
+// dst[r][0 .. pitch) = src[r][0 .. P), then -0 (times the +0 tail of the gathered rows: products of -0, which change no sum)
+__global__ __launch_bounds__(NT) void pad_rows(const float *__restrict__ src, float *__restrict__ dst, int64_t rows, int P,
+                                               int pitch) {
+  const int64_t total = rows * pitch;
+  for (int64_t i = gtid(); i < total; i += gstride()) {
+    const int64_t r = i / pitch;
+    const int p = (int)(i - r * pitch);
+    dst[i] = p < P ? src[r * P + p] : -0.0f;
+  }
+}
+
 __global__ __launch_bounds__(NT) void fill_zero(float *__restrict__ out, int64_t total) {
   for (int64_t i = gtid(); i < total; i += gstride()) out[i] = 0.f;
 }
@@ -486,7 +500,18 @@ int make_geo(const char *who, Geo &g, int64_t N, int64_t C, int64_t H, int64_t W
 // floats: packed weights (or the packed gradient) + the gathered operand of `chunk` images
 constexpr int64_t kColsCapFloats = (int64_t)1 << 30;  // 4 GiB of gathered operand per chunk at most
 
-void ws_layout(int kind, const Geo &g, int64_t &w_floats, int64_t &per_img) {
+// Weight update: the chain of one image is OH*OW products long.  Where the GEMM runs on the large-tile kernels (k tiles
+// of 32) and OH*OW is not a multiple of 32 (14 x 14, 7 x 7 planes), both operands are laid out with rows of Pp floats,
+// padded with -0 (gout, copied) and +0 (the gathered rows): the extra products are -0 and change no sum, and the GEMM
+// runs its unchecked-load kernel (measured, chain GEMM at batch 32: 256 x 2304 over 196 -> 224: 0.216 -> 0.137 ms,
+// 512 x 4608 over 49 -> 64: 0.198 -> 0.107 ms).  The small-tile kernels mask a ragged tile cheaply: no padding there.
+int64_t wu_pitch(const Geo &g, int variant) {
+  const int64_t P = g.OH * g.OW;
+  if (P % 32 == 0 || fpemu_gemm_tile_edge_(g.K, g.C * g.R * g.S, 1, variant) < 64) return P;
+  return (P + 31) / 32 * 32;
+}
+
+void ws_layout(int kind, const Geo &g, int variant, int64_t &w_floats, int64_t &per_img) {
   if (kind == FPEMU_CONV_BP) {
     w_floats = g.C * g.K * g.R * g.S;
     per_img = g.K * g.R * g.S * g.H * g.W;
@@ -494,8 +519,9 @@ void ws_layout(int kind, const Geo &g, int64_t &w_floats, int64_t &per_img) {
     w_floats = g.K * g.KP;
     per_img = g.KP * g.OH * g.OW;
   } else {
+    const int64_t P = g.OH * g.OW, Pp = wu_pitch(g, variant);
     w_floats = g.K * g.C * g.R * g.S;
-    per_img = g.C * g.R * g.S * g.OH * g.OW;
+    per_img = g.C * g.R * g.S * Pp + (Pp != P ? g.K * Pp : 0);   // gathered rows (+ the padded copy of gout)
   }
   w_floats = (w_floats + 63) & ~(int64_t)63;  // keep the gathered operand 256-byte aligned
 }
@@ -582,8 +608,10 @@ uint64_t fpemu_conv2d_workspace_bytes(int kind, int64_t N, int64_t C, int64_t H,
   Geo g;
   if (kind < FPEMU_CONV_FP || kind > FPEMU_CONV_WU) return 0;
   if (make_geo("fpemu_conv2d_workspace_bytes", g, N, C, H, W, K, R, S, stride, pad) != FPEMU_OK) return 0;
-  int64_t wf, per;
-  ws_layout(kind, g, wf, per);
+  int64_t wf, per, per0;
+  ws_layout(kind, g, 1, wf, per);
+  ws_layout(kind, g, 0, wf, per0);   // (the call's variant is not known here: the larger of the two layouts)
+  if (per0 > per) per = per0;
   int64_t imgs = per > 0 ? kColsCapFloats / per : N;
   if (imgs < 1) imgs = 1;
   if (imgs > N) imgs = N;
@@ -602,7 +630,7 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   if (!out || !in || !w || !ws) return fail(who, FPEMU_EINVAL, "null buffer");
   if ((uintptr_t)ws % 16u) return fail(who, FPEMU_EALIGN, "workspace not 16-byte aligned");
   int64_t wf, per;
-  ws_layout(FPEMU_CONV_FP, g, wf, per);
+  ws_layout(FPEMU_CONV_FP, g, variant, wf, per);
   const int64_t chunk = chunk_images(g, per, (int64_t)(ws_bytes / 4) - wf);
   if ((int64_t)(ws_bytes / 4) < wf) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   hipStream_t s = (hipStream_t)stream;
@@ -622,7 +650,7 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
     hipLaunchKernelGGL(pick_cols_fp(P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, stride), gather_grid(P, nb * kp),
-                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * kp, (int)kp);
+                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * kp, (int)kp, (int)P);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_start_launch_(out + n0 * K * P, Wm, cols, K, P, kp, kp, P, P, 0, 0, variant, nb, 0, kp * P,
                                         K * P, 1, 0, 0, start, bias, stream);
@@ -642,7 +670,7 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
   if (!gin || !gout || !w || !ws) return fail(who, FPEMU_EINVAL, "null buffer");
   if ((uintptr_t)ws % 16u) return fail(who, FPEMU_EALIGN, "workspace not 16-byte aligned");
   int64_t wf, per;
-  ws_layout(FPEMU_CONV_BP, g, wf, per);
+  ws_layout(FPEMU_CONV_BP, g, variant, wf, per);
   const int64_t chunk = chunk_images(g, per, (int64_t)(ws_bytes / 4) - wf);
   if ((int64_t)(ws_bytes / 4) < wf) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   hipStream_t s = (hipStream_t)stream;
@@ -694,12 +722,12 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
   if (!gw || !ws || (N > 0 && (!gout || !in))) return fail(who, FPEMU_EINVAL, "null buffer");
   if ((uintptr_t)ws % 16u) return fail(who, FPEMU_EALIGN, "workspace not 16-byte aligned");
   int64_t wf, per;
-  ws_layout(FPEMU_CONV_WU, g, wf, per);
+  ws_layout(FPEMU_CONV_WU, g, variant, wf, per);
   const int64_t chunk = N == 0 ? 1 : chunk_images(g, per, (int64_t)(ws_bytes / 4) - wf);
   if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   hipStream_t s = (hipStream_t)stream;
   float *Gm = (float *)ws, *cols = Gm + wf;
-  const int64_t P = g.OH * g.OW, crs = C * R * S;
+  const int64_t P = g.OH * g.OW, crs = C * R * S, Pp = wu_pitch(g, variant);
   if (N == 0) {  // no image: the gradient is +0
     hipLaunchKernelGGL(fill_zero, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, K * crs);
     CHECK_LAUNCH(who);
@@ -707,12 +735,19 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
     hipLaunchKernelGGL(pick_cols_fp(P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, stride), gather_grid(P, nb * crs),
-                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs, (int)crs);
+                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs, (int)crs, (int)Pp);
     CHECK_LAUNCH(who);
+    const float *ga = gout + n0 * K * P;
+    if (Pp != P) {  // rows of gout with a tail of -0 up to whole k tiles (behind the chunk's gathered rows)
+      float *gp = cols + nb * crs * Pp;
+      hipLaunchKernelGGL(pad_rows, dim3(blocks_for(nb * K * Pp)), dim3(NT), 0, s, ga, gp, nb * K, (int)P, (int)Pp);
+      CHECK_LAUNCH(who);
+      ga = gp;
+    }
     // one chain across the chunk's images in ONE launch: k segments = images (chunks follow in order)
     // (the first chunk's chains start at +0, the later ones where the chunk before left them)
-    rc = fpemu_gemm_chain_start_launch_(Gm, gout + n0 * K * P, cols, K, crs, P, P, P, crs, 0, 1, variant, 1, 0, 0, 0, nb,
-                                        K * P, crs * P, n0 == 0 ? 3 : 0, nullptr, stream);
+    rc = fpemu_gemm_chain_start_launch_(Gm, ga, cols, K, crs, Pp, Pp, Pp, crs, 0, 1, variant, 1, 0, 0, 0, nb,
+                                        K * Pp, crs * Pp, n0 == 0 ? 3 : 0, nullptr, stream);
     if (rc != FPEMU_OK) return rc;
   }
   hipLaunchKernelGGL(unpack_gw, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, gw, g);

@@ -29,6 +29,7 @@
 #include "../../include/fpemu_hip.h"
 
 extern "C" void fpemu_set_error_(const char *msg);  // fpemu_hip.hip: thread-local error text
+extern "C" int fpemu_gemm_tile_edge_(int64_t M, int64_t N, int64_t batch, int variant);   // below, after the kernels
 
 namespace {
 
@@ -1434,21 +1435,8 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   const int c_vec = aligned16(C) && (ldc % 4 == 0) && (bt.sc % 4 == 0) && (N % 4 == 0);
   if (bt.nseg < 1) return fail(FPEMU_EINVAL, "k_segments must be >= 1");
   if (bt.nseg > 1 && ((bt.ka % 4) || (bt.kb % 4))) a.vec = b.vec = 0;
-  // Tile edge: 128 unless that leaves the chip mostly idle (fewer tiles than two per CU) -- a chain cannot
-  // be split along k, so small M x N problems get 64 x 64 tiles (MFMA kernel only).
-  const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch;
-  const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64) * batch;
-  // fewer 64 x 64 tiles than CUs: the chains are latency-bound -> 32 x 32 tiles of 16x16x4 MFMAs (gemm_mfma16_kernel)
-  const int64_t t32 = ((M + 31) / 32) * ((N + 31) / 32) * batch;
-  const bool small = variant == 1 && t64 < 256 && t32 <= FPEMU_GEMM_SMALL_MAX;  // up to ~1.25 waves per SIMD (measured: at 576 tiles
-                                                               // the 64 x 64 kernel is the faster one again)
-  // so few chains that even 32 x 32 tiles leave most CUs idle: 16 x 16 tiles, one chain per workgroup (a CU's load
-  // rate, not the chain, bounds a 32 x 32 tile: see gemm_mfma16ws_kernel)
-  const int64_t t16 = ((M + 15) / 16) * ((N + 15) / 16) * batch;
-  const bool tiny = small && FPEMU_GEMM_WS && t32 < FPEMU_GEMM_WS_TINY && t16 <= FPEMU_GEMM_WS_TINY16;
-  // (the VALU kernel: 64 x 64 tiles when 128 x 128 ones would leave CUs without a workgroup)
-  const int tb = tiny ? 16 : small ? SB : (variant == 1 && (t128 < 512 || M <= 64 || N <= 64)) ? 64
-               : (variant != 1 && t128 < FPEMU_SEQK_T64_BELOW) ? 64 : 128;
+  const int tb = fpemu_gemm_tile_edge_(M, N, batch, variant);   // 16 / 32: the small-tile chain kernels
+  const bool tiny = tb == 16, small = tb <= 32;
   const int tiles_m = (int)((M + tb - 1) / tb), tiles_n = (int)((N + tb - 1) / tb);
   const int64_t nwg = (int64_t)tiles_m * tiles_n;
   if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "too many tiles");
@@ -1492,6 +1480,28 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
 }
 
 }  // namespace
+
+// The tile edge for an M x N (x batch) problem: 16 / 32 (the small-tile chain kernels, whose k tiles are 128 deep) or
+// 64 / 128 (k tiles of 32; VALU kernel 16).  Also called by fpemu_conv.hip, which pads a ragged chain segment to whole
+// k tiles only where that puts the GEMM on an unchecked-load kernel.
+extern "C" int fpemu_gemm_tile_edge_(int64_t M, int64_t N, int64_t batch, int variant) {
+  // Tile edge: 128 unless that leaves the chip mostly idle (fewer tiles than two per CU) -- a chain cannot
+  // be split along k, so small M x N problems get 64 x 64 tiles (MFMA kernel only).
+  const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch;
+  const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64) * batch;
+  // fewer 64 x 64 tiles than CUs: the chains are latency-bound -> 32 x 32 tiles of 16x16x4 MFMAs (gemm_mfma16_kernel)
+  const int64_t t32 = ((M + 31) / 32) * ((N + 31) / 32) * batch;
+  const bool small = variant == 1 && t64 < 256 && t32 <= FPEMU_GEMM_SMALL_MAX;  // up to ~1.25 waves per SIMD (measured: at 576 tiles
+                                                               // the 64 x 64 kernel is the faster one again)
+  // so few chains that even 32 x 32 tiles leave most CUs idle: 16 x 16 tiles, one chain per workgroup (a CU's load
+  // rate, not the chain, bounds a 32 x 32 tile: see gemm_mfma16ws_kernel)
+  const int64_t t16 = ((M + 15) / 16) * ((N + 15) / 16) * batch;
+  const bool tiny = small && FPEMU_GEMM_WS && t32 < FPEMU_GEMM_WS_TINY && t16 <= FPEMU_GEMM_WS_TINY16;
+  // (the VALU kernel: 64 x 64 tiles when 128 x 128 ones would leave CUs without a workgroup)
+  return tiny ? 16 : small ? SB : (variant == 1 && (t128 < 512 || M <= 64 || N <= 64)) ? 64
+               : (variant != 1 && t128 < FPEMU_SEQK_T64_BELOW) ? 64 : 128;
+}
+
 
 // Internal to the library (fpemu_conv.hip): one implicit-convolution launch over `batch` images.
 //   out[b][m][oy][ox] = chain(bias[m]; for (cb, kj, ki, c2): Wm[m][((cb*R + kj)*S + ki)*64 + c2] *

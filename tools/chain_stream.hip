@@ -34,6 +34,14 @@ __global__ __launch_bounds__(64) void chain(float *out, int iters, int zero) {
           fa[c ^ 1][s] = T[o + ((q * 8 + s) & 31) * 64];
           const int o2 = (base | ((it >> 1) & 1)) + lane;
           fb[c ^ 1][s] = T[4096 + o2 + ((q * 8 + s) & 31) * 64];
+        } else if constexpr (MODE == 4) {   // reads as in (L), plus ONE VALU write to a source register of the MFMA just issued
+          asm volatile("v_or_b32 %0, %0, %1" : "+v"(fa[c][s]) : "v"(zero));
+          fa[c ^ 1][s] = T[base + lane + ((q * 8 + s) & 31) * 64];
+          fb[c ^ 1][s] = T[base + 4096 + lane + ((q * 8 + s) & 31) * 64];
+        } else if constexpr (MODE == 5) {   // ... to a register the MFMA does not read
+          asm volatile("v_or_b32 %0, %0, %1" : "+v"(base) : "v"(zero));
+          fa[c ^ 1][s] = T[base + lane + ((q * 8 + s) & 31) * 64];
+          fb[c ^ 1][s] = T[base + 4096 + lane + ((q * 8 + s) & 31) * 64];
         } else if constexpr (MODE == 3) {   // both fragments in one ds_read2st64 (A and B images 4096 words apart)
           const float *p = &T[base + lane + ((q * 8 + s) & 31) * 64];
           fa[c ^ 1][s] = p[0];
@@ -127,11 +135,13 @@ int main() {
   run_barrier<1>(out, e0, e1, 144);
   run_barrier<4>(out, e0, e1, 144);
   run_barrier<8>(out, e0, e1, 144);
-  for (int wgs : {144, 256}) {
+  for (int wgs : {144}) {
     run<0>("MFMA chain only", out, e0, e1, wgs);
     run<1>("+ 2 ds_read_b32 per step", out, e0, e1, wgs);
     run<2>("+ 2 ds_read_b32 + 2 VALU address ops per step", out, e0, e1, wgs);
     run<3>("+ 1 ds_read2st64_b32 per step", out, e0, e1, wgs);
+    run<4>("+ 2 reads + a VALU write to the MFMA's source", out, e0, e1, wgs);
+    run<5>("+ 2 reads + a VALU write to another register", out, e0, e1, wgs);
   }
   return 0;
 }
