@@ -94,6 +94,68 @@ __global__ __launch_bounds__(64 * (1 + EXTRA)) void chain_barrier(float *out, in
   if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[threadIdx.x] = acc[0];
 }
 
+// The chain wave (wave 0) and ONE busy partner wave: wave PARTNER of eight issues NV VALU instructions per 32-step tile and
+// meets the barrier; the other waves leave at once.  PARTNER = 4 shares the chain's SIMD (waves go to the SIMDs in turn),
+// PARTNER = 1 sits on the next one.
+template <int PARTNER, int NV>
+__global__ __launch_bounds__(512) void chain_partner(float *out, int iters, int zero) {
+  __shared__ float T[8192];
+  for (int i = threadIdx.x; i < 8192; i += 512) T[i] = 1.0f + (float)(i & 7) * 0.125f;
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+  if (wave != 0 && wave != PARTNER) return;
+  if (wave == PARTNER) {
+    int x = threadIdx.x;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(zero));
+      __syncthreads();
+    }
+    if (x == 12345678) out[0] = 1.f;
+    return;
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int lane = threadIdx.x;
+  float fa[2][8], fb[2][8];
+  for (int s = 0; s < 8; s++) { fa[0][s] = T[lane + s * 64]; fb[0][s] = T[4096 + lane + s * 64]; }
+  int base = zero;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = q & 1;
+#pragma unroll
+      for (int s = 0; s < 8; s++) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c][s], fb[c][s], acc, 0, 0, 0);
+        fa[c ^ 1][s] = T[base + lane + ((q * 8 + s) & 31) * 64];
+        fb[c ^ 1][s] = T[base + 4096 + lane + ((q * 8 + s) & 31) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (q == 2) {
+#pragma unroll
+        for (int s = 0; s < 8; s++) asm volatile("" : "+v"(fa[c ^ 1][s]), "+v"(fb[c ^ 1][s]));
+        __syncthreads();
+      }
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[threadIdx.x] = acc[0];
+}
+
+template <int PARTNER, int NV> void run_partner(float *out, hipEvent_t e0, hipEvent_t e1) {
+  const int iters = 20000;
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((chain_partner<PARTNER, NV>), dim3(144), dim3(512), 0, 0, out, iters, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+  }
+  printf("chain + partner wave %d issuing %3d VALU instructions per 32 steps: %.3f ms  %.1f ns per step\n", PARTNER, NV, best,
+         best * 1e6 / (iters * 32.0));
+}
+
 template <int EXTRA> void run_barrier(float *out, hipEvent_t e0, hipEvent_t e1, int wgs) {
   const int iters = 20000;
   float best = 1e30f;
@@ -131,6 +193,12 @@ int main() {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  run_partner<4, 0>(out, e0, e1);
+  run_partner<4, 8>(out, e0, e1);
+  run_partner<4, 32>(out, e0, e1);
+  run_partner<4, 128>(out, e0, e1);
+  run_partner<1, 32>(out, e0, e1);
+  run_partner<1, 128>(out, e0, e1);
   run_barrier<0>(out, e0, e1, 144);
   run_barrier<1>(out, e0, e1, 144);
   run_barrier<4>(out, e0, e1, 144);
