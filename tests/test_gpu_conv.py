@@ -160,6 +160,31 @@ def test_conv_small_workspace_chunks(hip):
                                  ws.data_ptr(), one, None) == -1   # C = 96: undefined in the reference
 
 
+@pytest.mark.parametrize("bname,variant,fused", VARIANTS)
+def test_conv_wu_chunked_padded_segments(hip, bname, variant, fused):
+    """Weight update with a workspace for two images of five: the chain continues from chunk to chunk.  7 x 7 planes
+    (49 products per image): the separate-rounding variant pads its operands to 64 per image (large-tile kernel), the
+    MFMA variant here takes the small-tile kernel, unpadded -- same bits as the oracle either way, and as one chunk."""
+    N, C, H, W, K, R, S, st, pd = 5, 64, 7, 7, 64, 3, 3, 1, 1
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    go = rng.standard_normal((N, K, H, W)).astype(np.float32)
+    L = hip.lib()
+    dims = (N, C, H, W, K, R, S, st, pd)
+    want = orc.conv2d_wu(go, x, (R, S), st, pd, fused)
+    tx, tg = _t(x), _t(go)
+    full = L.fpemu_conv2d_workspace_bytes(2, *dims)
+    two = L.fpemu_conv2d_workspace_bytes(2, 2, *dims[1:])
+    assert two < full
+    for nbytes in (full, two):
+        ws = torch.empty(nbytes // 4, device=DEV)
+        gw = torch.empty(K, C, R, S, device=DEV)
+        assert L.fpemu_conv2d_wu_f32(gw.data_ptr(), tg.data_ptr(), tx.data_ptr(), *dims, variant, ws.data_ptr(), nbytes,
+                                     None) == 0, L.fpemu_last_error()
+        torch.cuda.synchronize()
+        assert_bits_equal(gw.cpu().numpy(), want, "%s workspace %d" % (bname, nbytes))
+
+
 def test_simple_conv2d_module_api(hip):
     """mpemu.cmodel.simple.conv2d with autograd, the call torch.nn.functional.conv2d is patched to."""
     from mpemu.cmodel import simple
