@@ -104,8 +104,8 @@ __device__ __forceinline__ void tile_load(const Operand &X, const float *base, i
     if constexpr (KCONT) {
       if (r < X.R) {
         const float *src = base + (int64_t)r * X.ld + k;
-        if (X.vec && k + 3 < X.K) {
-          t = *reinterpret_cast<const f32x4 *>(src);
+        if (k + 3 < X.K) {  // four elements inside the matrix: one load, aligned or not (a 4-byte-aligned dwordx4 is
+          t = *reinterpret_cast<const f32x4u *>(src);   // legal; rows of a matrix whose ld is not a multiple of 4 need it)
         } else {
 #pragma unroll
           for (int c = 0; c < 4; c++)
@@ -115,8 +115,8 @@ __device__ __forceinline__ void tile_load(const Operand &X, const float *base, i
     } else {
       if (k < X.K) {
         const float *src = base + (int64_t)k * X.ld + r;
-        if (X.vec && r + 3 < X.R) {
-          t = *reinterpret_cast<const f32x4 *>(src);
+        if (r + 3 < X.R) {
+          t = *reinterpret_cast<const f32x4u *>(src);
         } else {
 #pragma unroll
           for (int c = 0; c < 4; c++)
@@ -811,8 +811,8 @@ __device__ __forceinline__ f32x4 small_load_one(const Operand &X, const float *b
   const bool in_outer = KCONT ? (r < X.R) : (k < X.K);
   const int inner = KCONT ? k : r, inner_end = KCONT ? X.K : X.R;
   if (in_outer) {
-    if (X.vec && inner + 3 < inner_end) {
-      t = *reinterpret_cast<const f32x4 *>(src);
+    if (inner + 3 < inner_end) {
+      t = *reinterpret_cast<const f32x4u *>(src);
     } else {
 #pragma unroll
       for (int c = 0; c < 4; c++)
@@ -1099,9 +1099,13 @@ __device__ __forceinline__ f32x4 ws_load_checked(const Operand &X, const float *
   const bool in_outer = KCONT ? (r < X.R) : (k < X.K);
   const int inner = KCONT ? k : r, inner_end = KCONT ? X.K : X.R;
   if (in_outer) {
+    if (inner + 3 < inner_end) {
+      v = *reinterpret_cast<const f32x4u *>(src);
+    } else {
 #pragma unroll
-    for (int c = 0; c < 4; c++)
-      if (inner + c < inner_end) v[c] = src[c];
+      for (int c = 0; c < 4; c++)
+        if (inner + c < inner_end) v[c] = src[c];
+    }
   }
   return v;
 }
