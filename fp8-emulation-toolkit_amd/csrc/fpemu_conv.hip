@@ -231,6 +231,86 @@ __global__ __launch_bounds__(NT) void cols_bp(const float *__restrict__ go, floa
   }
 }
 
+// ---- Backward-data with stride > 1, by PHASE of the stride -------------------------------------------------------
+// Input pixels (y, x) with y = yh * st + py, x = xh * st + px see only the taps kj = (py + pad) mod st, + st, ... and
+// ki = (px + pad) mod st, + st, ...; for those oj = yh + (py + pad - kj) / st (exact) -- a stride-1 correlation of
+// gout with a sub-filter.  The gathered form above multiplies the other taps in as zeros: st * st times the flops and
+// a gathered operand st * st times the size (ResNet-50's 3 x 3 stride-2 layers: 0.48-0.56 ms at batch 32 against
+// 0.1 ms for their stride-1 twins).  Here each phase is its own chain GEMM over its own taps in the reference's order
+// (ob, oj ascending = kj descending, ki ascending, o2) -- exactly the products the reference forms, it skips taps that
+// do not exist (simple_conv2d_impl.cpp:505-560) -- into a phase plane; one pass then interleaves the planes into gin.
+struct Phase {
+  int py, px;      // residues of y and x
+  int kj0, ki0;    // smallest filter row / column of this phase
+  int nj, ni;      // filter rows / columns of this phase (0: no tap -> the phase's pixels are +0)
+  int Hh, Wh;      // pixels of this phase: y = yh * st + py < H, x = xh * st + px < W
+  int pitch;       // floats per row of the phase's gathered matrix and phase plane (Hh * Wh rounded up to whole tiles)
+};
+
+// Wph[c][(ob, aj, ai, o2)] = w[ob*KB + o2][c][kj][ki], kj = kj0 + (nj - 1 - aj) * st (descending), ki = ki0 + ai * st
+__global__ __launch_bounds__(NT) void pack_w_bp_phase(const float *__restrict__ w, float *__restrict__ Wm, Geo g, Phase ph) {
+  const int64_t krs = g.K * ph.nj * ph.ni, total = g.C * krs;
+  const int st = (int)g.stride;
+  for (int64_t i = gtid(); i < total; i += gstride()) {
+    const int64_t c = i / krs;
+    int64_t kk = i % krs;
+    const int64_t o2 = kk % g.KB; kk /= g.KB;
+    const int64_t ai = kk % ph.ni; kk /= ph.ni;
+    const int64_t aj = kk % ph.nj;
+    const int64_t ob = kk / ph.nj;
+    const int64_t kj = ph.kj0 + (ph.nj - 1 - aj) * st, ki = ph.ki0 + ai * st;
+    Wm[i] = w[(((ob * g.KB + o2) * g.C + c) * g.R + kj) * g.S + ki];
+  }
+}
+
+// colsp[n][(ob, aj, ai, o2)][(yh, xh)] = gout[n][ob*KB + o2][yh + dj][xh + di] (0 outside), rows of ph.pitch floats
+// with a +0 tail.  One gathered row per blockIdx.y, threads along the phase's pixels.
+__global__ __launch_bounds__(NT) void cols_bp_phase(const float *__restrict__ go, float *__restrict__ cols, Geo g, Phase ph,
+                                                    int64_t nrows) {
+  const int OH = (int)g.OH, OW = (int)g.OW, st = (int)g.stride, Wh = ph.Wh, HWp = ph.Hh * ph.Wh;
+  const int krs = (int)g.K * ph.nj * ph.ni;
+  for (int64_t row = blockIdx.y; row < nrows; row += gridDim.y) {
+    int kk = (int)(row % krs);
+    const int64_t n = row / krs;
+    const int o2 = kk % (int)g.KB; kk /= (int)g.KB;
+    const int ai = kk % ph.ni; kk /= ph.ni;
+    const int aj = kk % ph.nj;
+    const int ob = kk / ph.nj;
+    const int kj = ph.kj0 + (ph.nj - 1 - aj) * st, ki = ph.ki0 + ai * st;
+    const int dj = (ph.py + (int)g.pad - kj) / st, di = (ph.px + (int)g.pad - ki) / st;   // exact divisions
+    const float *src = go + (n * g.K + ob * g.KB + o2) * (int64_t)OH * OW;
+    float *dst = cols + row * ph.pitch;
+    for (int pix = blockIdx.x * NT + threadIdx.x; pix < ph.pitch; pix += gridDim.x * NT) {
+      float v = 0.f;
+      if (pix < HWp) {
+        const int yh = pix / Wh, xh = pix - yh * Wh;
+        const int oj = yh + dj, oi = xh + di;
+        if ((unsigned)oj < (unsigned)OH && (unsigned)oi < (unsigned)OW) v = src[oj * OW + oi];
+      }
+      dst[pix] = v;
+    }
+  }
+}
+
+// gin[n][c][y][x] = plane(y mod st, x mod st)[n][c][(y / st) * Wh + x / st]; +0 where the phase has no tap.
+struct PhaseTable {
+  const float *plane[16];   // by py * st + px (st <= 4); nullptr: no tap
+  int pitch[16], Wh[16];
+};
+__global__ __launch_bounds__(NT) void interleave_phases(float *__restrict__ gin, PhaseTable tb, int64_t planes, int H, int W,
+                                                        int st) {
+  const int64_t HW = (int64_t)H * W, total = planes * HW;
+  for (int64_t i = gtid(); i < total; i += gstride()) {
+    const int64_t pl = i / HW;
+    const int rem = (int)(i - pl * HW);
+    const int y = rem / W, x = rem - y * W;
+    const int p = (y % st) * st + (x % st);
+    float v = 0.f;
+    if (tb.plane[p] != nullptr) v = tb.plane[p][pl * tb.pitch[p] + (y / st) * tb.Wh[p] + x / st];
+    gin[i] = v;
+  }
+}
+
 // Implicit-GEMM path (stride 1, 64-channel blocks, fmaf-chain variant): instead of gathering R*S shifted copies
 // of every plane, zero-pad the planes ONCE; the chain GEMM then reads row (c, kj, ki) of its operand as plane c
 // shifted by kj*Wp + ki (fpemu_gemm.hip, ConvMap).  xp[n][c][y][x] = x[n][c][y - ph][x - pw], 0 outside.
@@ -500,6 +580,34 @@ int make_geo(const char *who, Geo &g, int64_t N, int64_t C, int64_t H, int64_t W
 // floats: packed weights (or the packed gradient) + the gathered operand of `chunk` images
 constexpr int64_t kColsCapFloats = (int64_t)1 << 30;  // 4 GiB of gathered operand per chunk at most
 
+// The phases of a strided backward-data convolution (see cols_bp_phase) and what they need per image: a plane per phase
+// plus the largest gathered matrix.  false: not a case for the phase path.
+constexpr int kMaxPhaseStride = 4;
+bool bp_by_phase(const Geo &g) { return g.stride > 1 && g.stride <= kMaxPhaseStride && g.C > 4; }
+Phase make_phase(const Geo &g, int py, int px) {
+  const int st = (int)g.stride, pad = (int)g.pad, R = (int)g.R, S = (int)g.S, H = (int)g.H, W = (int)g.W;
+  Phase ph;
+  ph.py = py; ph.px = px;
+  ph.kj0 = (py + pad) % st; ph.ki0 = (px + pad) % st;
+  ph.nj = ph.kj0 < R ? (R - 1 - ph.kj0) / st + 1 : 0;
+  ph.ni = ph.ki0 < S ? (S - 1 - ph.ki0) / st + 1 : 0;
+  ph.Hh = py < H ? (H - 1 - py) / st + 1 : 0;
+  ph.Wh = px < W ? (W - 1 - px) / st + 1 : 0;
+  ph.pitch = (ph.Hh * ph.Wh + 63) / 64 * 64;   // whole 64-column tiles: the GEMM drops its bounds tests
+  return ph;
+}
+void bp_phase_floats(const Geo &g, int64_t &planes, int64_t &gathered) {   // per image
+  planes = 0; gathered = 0;
+  for (int py = 0; py < (int)g.stride; py++)
+    for (int px = 0; px < (int)g.stride; px++) {
+      const Phase ph = make_phase(g, py, px);
+      if (ph.Hh * ph.Wh == 0 || ph.nj * ph.ni == 0) continue;
+      planes += g.C * ph.pitch;
+      const int64_t m = g.K * ph.nj * ph.ni * ph.pitch;
+      gathered = m > gathered ? m : gathered;
+    }
+}
+
 // Weight update: the chain of one image is OH*OW products long.  Where the GEMM runs on the large-tile kernels (k tiles
 // of 32) and OH*OW is not a multiple of 32 (14 x 14, 7 x 7 planes), both operands are laid out with rows of Pp floats,
 // padded with -0 (gout, copied) and +0 (the gathered rows): the extra products are -0 and change no sum, and the GEMM
@@ -515,6 +623,11 @@ void ws_layout(int kind, const Geo &g, int variant, int64_t &w_floats, int64_t &
   if (kind == FPEMU_CONV_BP) {
     w_floats = g.C * g.K * g.R * g.S;
     per_img = g.K * g.R * g.S * g.H * g.W;
+    if (bp_by_phase(g)) {
+      int64_t planes, gathered;
+      bp_phase_floats(g, planes, gathered);
+      per_img = planes + gathered;
+    }
   } else if (kind == FPEMU_CONV_FP) {
     w_floats = g.K * g.KP;
     per_img = g.KP * g.OH * g.OW;
@@ -698,6 +811,49 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
     if (rc != 1) return rc;
   }
   if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
+  if (bp_by_phase(g)) {
+    int64_t planes_per_img, gathered_per_img;
+    bp_phase_floats(g, planes_per_img, gathered_per_img);
+    const int st = (int)stride;
+    Phase phs[kMaxPhaseStride * kMaxPhaseStride];
+    float *wph[kMaxPhaseStride * kMaxPhaseStride];
+    {  // the phases' weights, packed once, side by side in the weight area (their taps partition the filter)
+      float *wp = Wm;
+      for (int p = 0; p < st * st; p++) {
+        phs[p] = make_phase(g, p / st, p % st);
+        wph[p] = nullptr;
+        const int64_t n = C * K * phs[p].nj * phs[p].ni;
+        if (phs[p].Hh * phs[p].Wh == 0 || n == 0) continue;
+        wph[p] = wp;
+        hipLaunchKernelGGL(pack_w_bp_phase, dim3(blocks_for(n)), dim3(NT), 0, s, w, wp, g, phs[p]);
+        CHECK_LAUNCH(who);
+        wp += n;
+      }
+    }
+    for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+      const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
+      float *plane = cols, *gath = cols + nb * planes_per_img;
+      PhaseTable tb;
+      for (int p = 0; p < 16; p++) { tb.plane[p] = nullptr; tb.pitch[p] = 0; tb.Wh[p] = 1; }
+      for (int p = 0; p < st * st; p++) {
+        if (wph[p] == nullptr) continue;
+        const Phase &ph = phs[p];
+        const int64_t krs_p = K * ph.nj * ph.ni;
+        hipLaunchKernelGGL(cols_bp_phase, gather_grid(ph.pitch, nb * krs_p), dim3(NT), 0, s, gout + n0 * K * P, gath, g, ph,
+                           nb * krs_p);
+        CHECK_LAUNCH(who);
+        rc = fpemu_gemm_chain_start_launch_(plane, wph[p], gath, C, ph.pitch, krs_p, krs_p, ph.pitch, ph.pitch, 0, 0,
+                                            variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3, nullptr, stream);
+        if (rc != FPEMU_OK) return rc;
+        tb.plane[p] = plane; tb.pitch[p] = ph.pitch; tb.Wh[p] = ph.Wh;
+        plane += nb * C * ph.pitch;
+      }
+      hipLaunchKernelGGL(interleave_phases, dim3(blocks_for(nb * C * HW)), dim3(NT), 0, s, gin + n0 * C * HW, tb, nb * C,
+                         (int)H, (int)W, st);
+      CHECK_LAUNCH(who);
+    }
+    return FPEMU_OK;
+  }
   hipLaunchKernelGGL(pack_w_bp, dim3(blocks_for(C * krs)), dim3(NT), 0, s, w, Wm, g);
   CHECK_LAUNCH(who);
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {

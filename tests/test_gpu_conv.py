@@ -68,6 +68,11 @@ def test_conv_vs_reference_fixture(hip, bname, variant, fused):
                                   # ... its channel batches of 8: an odd count, a tail, one batch and a tail
                                   (2, 3, 13, 17, 24, 3, 3, 2, 1), (1, 2, 11, 9, 20, 4, 4, 2, 1),
                                   (2, 1, 9, 9, 12, 3, 3, 1, 1),
+                                  # strided backward-data by phase of the stride (C > 4): stride 3 with a 5 x 5 filter,
+                                  # stride 4 with 1 x 1 (15 of 16 phases have no tap), even filter, no padding + odd width,
+                                  # a stride larger than the filter's reach
+                                  (2, 8, 11, 13, 16, 5, 5, 3, 2), (1, 8, 9, 9, 8, 1, 1, 4, 0), (2, 16, 10, 10, 16, 2, 2, 2, 0),
+                                  (1, 8, 9, 11, 8, 3, 3, 2, 0), (2, 64, 9, 9, 64, 2, 2, 3, 1),
                                   # weight update on the large-tile kernels with OH*OW = 196 not a multiple of 32: both
                                   # operands padded to 224 (the separate-rounding variant pads in most cases above)
                                   (3, 256, 14, 14, 256, 3, 3, 1, 1)])

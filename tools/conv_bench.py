@@ -10,7 +10,10 @@ from mpemu.pytquant.hip import _binding as hip  # noqa: E402
 hip._SO = os.environ.get("FPEMU_LIB") or hip._SO  # tuning aid: a library built with other constants
 
 LAYERS = [(32, 3, 224, 224, 64, 7, 7, 2, 3), (32, 64, 56, 56, 64, 3, 3, 1, 1), (32, 128, 28, 28, 128, 3, 3, 1, 1),
-          (32, 256, 14, 14, 256, 3, 3, 1, 1), (32, 512, 7, 7, 512, 3, 3, 1, 1), (32, 256, 56, 56, 64, 1, 1, 1, 0)]
+          (32, 256, 14, 14, 256, 3, 3, 1, 1), (32, 512, 7, 7, 512, 3, 3, 1, 1), (32, 256, 56, 56, 64, 1, 1, 1, 0),
+          # ResNet-50's strided layers (the gathered form): 3 x 3 stride 2, 1 x 1 stride 2 (downsample)
+          (32, 128, 56, 56, 128, 3, 3, 2, 1), (32, 256, 28, 28, 256, 3, 3, 2, 1), (32, 512, 14, 14, 512, 3, 3, 2, 1),
+          (32, 256, 56, 56, 512, 1, 1, 2, 0), (32, 512, 28, 28, 1024, 1, 1, 2, 0), (32, 1024, 14, 14, 2048, 1, 1, 2, 0)]
 
 
 def timed(fn, iters=3):
