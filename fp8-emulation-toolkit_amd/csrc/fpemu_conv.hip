@@ -38,7 +38,8 @@ extern "C" int fpemu_gemm_chain_start_launch_(float *C, const float *A, const fl
                                               int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans,
                                               int variant, int64_t batch, int64_t stride_a, int64_t stride_b,
                                               int64_t stride_c, int64_t k_segments, int64_t kseg_stride_a,
-                                              int64_t kseg_stride_b, int start, const float *init, void *stream);
+                                              int64_t kseg_stride_b, int start, const float *init, int64_t nstore,
+                                              void *stream);
 
 namespace {
 
@@ -619,6 +620,16 @@ int64_t wu_pitch(const Geo &g, int variant) {
   return (P + 31) / 32 * 32;
 }
 
+// Forward, gathered form: the gathered rows are OH*OW pixels long; where the GEMM runs on the large-tile kernels they
+// are padded with zero columns to whole tiles, so that every load is unchecked (the result keeps rows of OH*OW: the
+// GEMM computes the extra columns and does not store them, Batch.nstore).
+int64_t fp_pitch(const Geo &g, int variant) {
+  const int64_t P = g.OH * g.OW;
+  const int tile = fpemu_gemm_tile_edge_(g.K, P, g.N > 0 ? g.N : 1, variant);
+  if (tile < 64 || P % tile == 0) return P;
+  return (P + tile - 1) / tile * tile;
+}
+
 void ws_layout(int kind, const Geo &g, int variant, int64_t &w_floats, int64_t &per_img) {
   if (kind == FPEMU_CONV_BP) {
     w_floats = g.C * g.K * g.R * g.S;
@@ -630,7 +641,7 @@ void ws_layout(int kind, const Geo &g, int variant, int64_t &w_floats, int64_t &
     }
   } else if (kind == FPEMU_CONV_FP) {
     w_floats = g.K * g.KP;
-    per_img = g.KP * g.OH * g.OW;
+    per_img = g.KP * fp_pitch(g, variant);
   } else {
     const int64_t P = g.OH * g.OW, Pp = wu_pitch(g, variant);
     w_floats = g.K * g.C * g.R * g.S;
@@ -756,6 +767,7 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   }
   if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   const int64_t kp = g.KP;  // chain length with its zero tail
+  const int64_t Pp = fp_pitch(g, variant);   // pixels per gathered row with their zero tail
   hipLaunchKernelGGL(pack_w_fp, dim3(blocks_for(K * kp)), dim3(NT), 0, s, w, Wm, g);
   CHECK_LAUNCH(who);
   // the chains start at bias[k] (+0 when channel padding exists in the reference: turns a -0 bias into +0), or at +0
@@ -763,10 +775,10 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
     hipLaunchKernelGGL(pick_cols_fp(P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, stride), gather_grid(P, nb * kp),
-                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * kp, (int)kp, (int)P);
+                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * kp, (int)kp, (int)Pp);
     CHECK_LAUNCH(who);
-    rc = fpemu_gemm_chain_start_launch_(out + n0 * K * P, Wm, cols, K, P, kp, kp, P, P, 0, 0, variant, nb, 0, kp * P,
-                                        K * P, 1, 0, 0, start, bias, stream);
+    rc = fpemu_gemm_chain_start_launch_(out + n0 * K * P, Wm, cols, K, Pp, kp, kp, Pp, P, 0, 0, variant, nb, 0, kp * Pp,
+                                        K * P, 1, 0, 0, start, bias, Pp != P ? P : 0, stream);
     if (rc != FPEMU_OK) return rc;
   }
   return FPEMU_OK;
@@ -843,7 +855,7 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
                            nb * krs_p);
         CHECK_LAUNCH(who);
         rc = fpemu_gemm_chain_start_launch_(plane, wph[p], gath, C, ph.pitch, krs_p, krs_p, ph.pitch, ph.pitch, 0, 0,
-                                            variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3, nullptr, stream);
+                                            variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3, nullptr, 0, stream);
         if (rc != FPEMU_OK) return rc;
         tb.plane[p] = plane; tb.pitch[p] = ph.pitch; tb.Wh[p] = ph.Wh;
         plane += nb * C * ph.pitch;
@@ -862,7 +874,7 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
                        dim3(NT), 0, s, gout + n0 * K * P, cols, g, nb * krs);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_start_launch_(gin + n0 * C * HW, Wm, cols, C, HW, krs, krs, HW, HW, 0, 0, variant, nb, 0,
-                                        krs * HW, C * HW, 1, 0, 0, 3, nullptr, stream);   // chains start at +0
+                                        krs * HW, C * HW, 1, 0, 0, 3, nullptr, 0, stream);   // chains start at +0
     if (rc != FPEMU_OK) return rc;
   }
   return FPEMU_OK;
@@ -903,7 +915,7 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
     // one chain across the chunk's images in ONE launch: k segments = images (chunks follow in order)
     // (the first chunk's chains start at +0, the later ones where the chunk before left them)
     rc = fpemu_gemm_chain_start_launch_(Gm, ga, cols, K, crs, Pp, Pp, Pp, crs, 0, 1, variant, 1, 0, 0, 0, nb,
-                                        K * Pp, crs * Pp, n0 == 0 ? 3 : 0, nullptr, stream);
+                                        K * Pp, crs * Pp, n0 == 0 ? 3 : 0, nullptr, 0, stream);
     if (rc != FPEMU_OK) return rc;
   }
   hipLaunchKernelGGL(unpack_gw, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, gw, g);

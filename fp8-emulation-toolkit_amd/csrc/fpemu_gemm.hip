@@ -218,6 +218,9 @@ struct Batch {
   // becomes +0), 3 = at +0.  (1-3: C is written only -- the convolution's bias / zero fill and its read-back are gone)
   int start;
   const float *init;
+  // Columns >= nstore (when nonzero) are computed but not stored: B is padded with zero columns to whole tiles so that
+  // every load is unchecked, while C keeps its own row length (the convolution's forward result: rows of OH*OW).
+  int nstore;
 };
 
 __device__ __forceinline__ float chain_start(const Batch &bt, const float *C, int64_t idx, int row) {
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
         if constexpr (CHAIN) {
 #pragma unroll
           for (int jj = 0; jj < 4; jj++)
-            if (c + jj < N) dst[jj] = acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1];
+            if (c + jj < N && (bt.nstore == 0 || c + jj < bt.nstore)) dst[jj] = acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1];
         } else if (c_vec && c + 3 < N) {
           f32x4 ci = *reinterpret_cast<const f32x4 *>(dst), o;
 #pragma unroll
@@ -700,7 +703,7 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
         for (int r = 0; r < 16; r++) {
           const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int col = n0 + wn + j * 32 + li;
-          if (FULL || (row < M && col < N)) C[(int64_t)row * ldc + col] = acc[i][j][r];
+          if ((FULL || (row < M && col < N)) && (bt.nstore == 0 || col < bt.nstore)) C[(int64_t)row * ldc + col] = acc[i][j][r];
         }
   } else {
     // per 32x32 MFMA tile: its 16 reads of C first (independent), then the 16 read-modify-writes -- one
@@ -996,7 +999,7 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = m0 + wm + 4 * lk + r;
-    if (FULL || (row < M && col < N)) {
+    if ((FULL || (row < M && col < N)) && (bt.nstore == 0 || col < bt.nstore)) {
       float *dst = C + (int64_t)row * ldc + col;
       if constexpr (CHAIN) *dst = acc[r];
       else *dst = epilogue(*dst, acc[r], alpha, beta);
@@ -1353,7 +1356,7 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = m0 + wm + 4 * lk + r;
-    if (MODE == 2 || (row < M && col < N)) {
+    if ((MODE == 2 || (row < M && col < N)) && (bt.nstore == 0 || col < bt.nstore)) {
       float *dst = C + (int64_t)row * ldc + col;
       if constexpr (CHAIN) *dst = acc[r];
       else *dst = epilogue(*dst, acc[r], alpha, beta);
@@ -1559,17 +1562,20 @@ extern "C" int fpemu_gemm_chain_f32(float *C, const float *A, const float *B, in
 }
 
 // fpemu_gemm_chain_f32 with the chains' starting values given instead of read from C (library-internal, used by
-// fpemu_conv.hip's gathered forms): start 1 = init[row], 2 = init[row] + 0.0f, 3 = +0 (init unused).  C is only written.
+// fpemu_conv.hip's gathered forms): start 1 = init[row], 2 = init[row] + 0.0f, 3 = +0 (init unused).  C is only written,
+// and only its first nstore columns when nstore != 0 (Batch.nstore).
 extern "C" int fpemu_gemm_chain_start_launch_(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
                                               int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans,
                                               int variant, int64_t batch, int64_t stride_a, int64_t stride_b,
                                               int64_t stride_c, int64_t k_segments, int64_t kseg_stride_a,
-                                              int64_t kseg_stride_b, int start, const float *init, void *stream) {
-  if (k_segments < 1 || k_segments > 0x7FFFFFFF || start < 0 || start > 3 || ((start == 1 || start == 2) && !init)) {
+                                              int64_t kseg_stride_b, int start, const float *init, int64_t nstore,
+                                              void *stream) {
+  if (k_segments < 1 || k_segments > 0x7FFFFFFF || start < 0 || start > 3 || ((start == 1 || start == 2) && !init) ||
+      nstore < 0 || nstore > N || (nstore != 0 && start == 0)) {
     fpemu_set_error_("fpemu_gemm_chain_start_launch_: bad k_segments / start");
     return FPEMU_EINVAL;
   }
   return launch_gemm("fpemu_gemm_chain_f32", C, A, B, M, N, K, lda, ldb, ldc, 1.0f, a_trans, b_trans, variant, true, batch,
-                     Batch{stride_a, stride_b, stride_c, kseg_stride_a, kseg_stride_b, (int)k_segments, start, init},
+                     Batch{stride_a, stride_b, stride_c, kseg_stride_a, kseg_stride_b, (int)k_segments, start, init, (int)nstore},
                      stream);
 }
