@@ -19,8 +19,9 @@
 //   wu: Gw      (K x CRS)    = chain(Gw;         gout[n] (K x P)  @ cols[n]^T (P x CRS))    k segments n = 0, 1, ...
 // cols / colsb are gathered by the kernels below (zero for padding taps: the reference multiplies its
 // zero padding in as well; for bp taps that do not exist for a pixel contribute w * 0, which leaves a
-// chain that started at +0 unchanged for every finite w).  Everything here is HBM-bound gather work;
-// the flops are in fpemu_gemm.hip.
+// chain that started at +0 unchanged for every finite w -- with stride > 1 and more than 4 channels bp runs
+// by phase of the stride over the existing taps only, see cols_bp_phase).  Everything here is HBM-bound
+// gather work; the flops are in fpemu_gemm.hip.
 //
 // Reference defects NOT reproduced: with C < 64 (or K < 64) and N > 1 the reference's
 // packing routines index images with C/64 = 0 and collapse the batch (:154, :242); here every image is
