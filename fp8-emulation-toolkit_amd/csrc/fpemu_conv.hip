@@ -282,14 +282,26 @@ __global__ __launch_bounds__(NT) void cols_bp_phase(const float *__restrict__ go
     const int dj = (ph.py + (int)g.pad - kj) / st, di = (ph.px + (int)g.pad - ki) / st;   // exact divisions
     const float *src = go + (n * g.K + ob * g.KB + o2) * (int64_t)OH * OW;
     float *dst = cols + row * ph.pitch;
-    for (int pix = blockIdx.x * NT + threadIdx.x; pix < ph.pitch; pix += gridDim.x * NT) {
-      float v = 0.f;
+    // four pixels per lane and one 16-byte store (the pitch is a multiple of 64); four pixels of one plane row that all
+    // exist come from one 4-byte-aligned 16-byte load
+    for (int pix = (blockIdx.x * NT + threadIdx.x) * 4; pix < ph.pitch; pix += gridDim.x * NT * 4) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
       if (pix < HWp) {
-        const int yh = pix / Wh, xh = pix - yh * Wh;
+        int yh = pix / Wh, xh = pix - yh * Wh;
         const int oj = yh + dj, oi = xh + di;
-        if ((unsigned)oj < (unsigned)OH && (unsigned)oi < (unsigned)OW) v = src[oj * OW + oi];
+        if (xh + 3 < Wh && (unsigned)oj < (unsigned)OH && oi >= 0 && oi + 3 < OW) {
+          const f32x4u a = *reinterpret_cast<const f32x4u *>(src + oj * OW + oi);
+          o = f32x4{a[0], a[1], a[2], a[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int qj = yh + dj, qi = xh + di;
+            if (pix + e < HWp && (unsigned)qj < (unsigned)OH && (unsigned)qi < (unsigned)OW) o[e] = src[qj * OW + qi];
+            if (++xh == Wh) { xh = 0; yh++; }
+          }
+        }
       }
-      dst[pix] = v;
+      *reinterpret_cast<f32x4 *>(dst + pix) = o;
     }
   }
 }
@@ -299,17 +311,37 @@ struct PhaseTable {
   const float *plane[16];   // by py * st + px (st <= 4); nullptr: no tap
   int pitch[16], Wh[16];
 };
+// A thread takes the st pixels x = xh * st .. xh * st + st - 1 of a row: one coalesced read per phase plane, st
+// consecutive floats written (one 8-byte store for stride 2 and an even width).
+template <int ST>
 __global__ __launch_bounds__(NT) void interleave_phases(float *__restrict__ gin, PhaseTable tb, int64_t planes, int H, int W,
-                                                        int st) {
-  const int64_t HW = (int64_t)H * W, total = planes * HW;
+                                                        int st_rt) {
+  const int st = ST ? ST : st_rt;
+  const int Wq = (W + st - 1) / st;
+  const int64_t per_plane = (int64_t)H * Wq, total = planes * per_plane;
   for (int64_t i = gtid(); i < total; i += gstride()) {
-    const int64_t pl = i / HW;
-    const int rem = (int)(i - pl * HW);
-    const int y = rem / W, x = rem - y * W;
-    const int p = (y % st) * st + (x % st);
-    float v = 0.f;
-    if (tb.plane[p] != nullptr) v = tb.plane[p][pl * tb.pitch[p] + (y / st) * tb.Wh[p] + x / st];
-    gin[i] = v;
+    const int64_t pl = i / per_plane;
+    const int rem = (int)(i - pl * per_plane);
+    const int y = rem / Wq, xh = rem - y * Wq;
+    const int py = y % st, yh = y / st;
+    float *dst = gin + (pl * H + y) * (int64_t)W + xh * st;
+    float v[ST ? ST : 4];
+#pragma unroll
+    for (int px = 0; px < (ST ? ST : 4); px++) {
+      v[px] = 0.f;
+      if (px < st && xh * st + px < W) {
+        const int p = py * st + px;
+        if (tb.plane[p] != nullptr) v[px] = tb.plane[p][pl * tb.pitch[p] + yh * tb.Wh[p] + xh];
+      }
+    }
+    if (ST == 2 && (W & 1) == 0 && ((uintptr_t)gin & 7u) == 0) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<f32x2 *>(dst) = f32x2{v[0], v[1]};
+    } else {
+#pragma unroll
+      for (int px = 0; px < (ST ? ST : 4); px++)
+        if (px < st && xh * st + px < W) dst[px] = v[px];
+    }
   }
 }
 
@@ -852,8 +884,8 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
         if (wph[p] == nullptr) continue;
         const Phase &ph = phs[p];
         const int64_t krs_p = K * ph.nj * ph.ni;
-        hipLaunchKernelGGL(cols_bp_phase, gather_grid(ph.pitch, nb * krs_p), dim3(NT), 0, s, gout + n0 * K * P, gath, g, ph,
-                           nb * krs_p);
+        hipLaunchKernelGGL(cols_bp_phase, gather_grid(ph.pitch / 4, nb * krs_p), dim3(NT), 0, s, gout + n0 * K * P, gath, g,
+                           ph, nb * krs_p);
         CHECK_LAUNCH(who);
         rc = fpemu_gemm_chain_start_launch_(plane, wph[p], gath, C, ph.pitch, krs_p, krs_p, ph.pitch, ph.pitch, 0, 0,
                                             variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3, nullptr, 0, stream);
@@ -861,7 +893,8 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
         tb.plane[p] = plane; tb.pitch[p] = ph.pitch; tb.Wh[p] = ph.Wh;
         plane += nb * C * ph.pitch;
       }
-      hipLaunchKernelGGL(interleave_phases, dim3(blocks_for(nb * C * HW)), dim3(NT), 0, s, gin + n0 * C * HW, tb, nb * C,
+      hipLaunchKernelGGL(st == 2 ? interleave_phases<2> : interleave_phases<0>,
+                         dim3(blocks_for(nb * C * H * ((W + st - 1) / st))), dim3(NT), 0, s, gin + n0 * C * HW, tb, nb * C,
                          (int)H, (int)W, st);
       CHECK_LAUNCH(who);
     }
