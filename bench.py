@@ -571,6 +571,23 @@ def main():
                 extras["conv_wu_3x3_c64_56"] = {"ms": round(w_avg, 5), "TFLOP/s_effective": round(fl / (w_avg * 1e-3) / 1e12, 2),
                                                 "verified": verified["conv_wu_3x3_c64_56"], "verified_on": "2 of the 32 images (same kernel)"}
                 del ci, cw, cb, co, go, gw, gw2
+                # backward-data of a STRIDED layer (3x3 stride 2, 128 -> 128 channels, 56 x 56 -> 28 x 28): one chain GEMM per
+                # phase of the stride over the taps that exist
+                sw = torch.randn(128, 128, 3, 3, device=dev) * 0.05
+                sgo = torch.randn(N_, 128, 28, 28, device=dev)
+                sgi = torch.empty(N_, 128, 56, 56, device=dev)
+
+                def bp_step():
+                    hip.conv2d_bp_(sgi, sgo, sw, 2, 1)
+
+                bp_step()
+                b_avg, _ = time_launches(bp_step, 5)
+                want = orc.conv2d_bp(sgo[:1].cpu().numpy(), sw.cpu().numpy(), (56, 56), 2, 1, fused=True)
+                verified["conv_bp_3x3_s2_c128_56"] = same(sgi[:1].contiguous(), want)
+                fl2 = 2.0 * N_ * 128 * 28 * 28 * 128 * 9
+                extras["conv_bp_3x3_s2_c128_56"] = {"ms": round(b_avg, 5), "TFLOP/s_effective": round(fl2 / (b_avg * 1e-3) / 1e12, 2),
+                                                    "verified": verified["conv_bp_3x3_s2_c128_56"]}
+                del sw, sgo, sgi
             except Exception as e:  # the conv leg must never take the bench line down
                 extras["conv_fp_3x3_c64_56"] = "failed: %r" % (e,)
                 verified["conv_fp_3x3_c64_56"] = False
