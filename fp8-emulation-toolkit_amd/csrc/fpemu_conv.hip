@@ -115,72 +115,95 @@ __global__ __launch_bounds__(NT) void pack_w_bp(const float *__restrict__ w, flo
 // 4 / 7 contiguous floats (one / two wide 4-byte-aligned loads instead of four loads with a bounds test each).
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
-template <bool vec4, int ST>
+// RB = rows per block trip: RB consecutive rows are RB channels of one filter tap (the channel index runs fastest), so
+// they share every index and bounds computation and their loads are issued together -- a block that gathers one short
+// row lives one memory round trip per few KiB (measured on the strided layers: 57 us for 122 MB with RB = 1).  RB = 4
+// needs the channel block and the rows per image to be multiples of 4 (checked on the host).
+template <bool vec4, int ST, int RB>
 __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float *__restrict__ cols, Geo g,
                                               int64_t nrows, int rows_per_img, int pitch) {
   // pitch: floats per gathered row, >= OH*OW (weight update: OH*OW padded to whole k tiles; the tail is +0)
   const int P = (int)(g.OH * g.OW), OW = (int)g.OW, H = (int)g.H, W = (int)g.W, st = (int)g.stride;
   const int crs = (int)(g.C * g.R * g.S);
-  for (int64_t row = blockIdx.y; row < nrows; row += gridDim.y) {
+  const int64_t HW = (int64_t)H * W;
+  for (int64_t row = (int64_t)blockIdx.y * RB; row < nrows; row += (int64_t)gridDim.y * RB) {
     int kk = (int)(row % rows_per_img);
     const int64_t n = row / rows_per_img;
+    float *dst = cols + row * pitch;
     if (kk >= crs) {  // the zero rows that pad the chain to whole k tiles (forward: rows_per_img = KP)
-      float *z = cols + row * pitch;
-      for (int p = blockIdx.x * NT + threadIdx.x; p < pitch; p += gridDim.x * NT) z[p] = 0.f;
+      for (int p = blockIdx.x * NT + threadIdx.x; p < pitch; p += gridDim.x * NT)
+#pragma unroll
+        for (int u = 0; u < RB; u++) dst[(int64_t)u * pitch + p] = 0.f;
       continue;
     }
     const int c2 = kk % (int)g.CB; kk /= (int)g.CB;
     const int ki = kk % (int)g.S; kk /= (int)g.S;
     const int kj = kk % (int)g.R;
     const int cb = kk / (int)g.R;
-    const float *src = x + (n * g.C + cb * g.CB + c2) * (int64_t)H * W;
-    float *dst = cols + row * pitch;
-    for (int p = P + blockIdx.x * NT + threadIdx.x; p < pitch; p += gridDim.x * NT) dst[p] = 0.f;
+    const float *src = x + (n * g.C + cb * g.CB + c2) * HW;   // rows u = 0 .. RB-1: planes c2 + u
+    for (int p = P + blockIdx.x * NT + threadIdx.x; p < pitch; p += gridDim.x * NT)
+#pragma unroll
+      for (int u = 0; u < RB; u++) dst[(int64_t)u * pitch + p] = 0.f;
     const int y0 = kj - (int)g.pad, x0 = ki - (int)g.pad;
     if constexpr (vec4) {  // four pixels per lane, one 16-byte store (rows are whole vectors and 16-byte aligned)
       for (int p = (blockIdx.x * NT + threadIdx.x) * 4; p < P; p += gridDim.x * NT * 4) {
-        f32x4 o;
+        f32x4 o[RB];
         int oj = p / OW, oi = p - oj * OW;
+        bool done = false;
         if constexpr (ST == 1 || ST == 2) {
           const int y = oj * ST + y0, xf = oi * ST + x0;
           if (oi + 3 < OW && (unsigned)y < (unsigned)H && xf >= 0 && xf + 3 * ST < W) {
             const float *q = src + y * W + xf;
             if constexpr (ST == 1) {
-              const f32x4u a = *reinterpret_cast<const f32x4u *>(q);
-              o = f32x4{a[0], a[1], a[2], a[3]};
+              f32x4u a[RB];
+#pragma unroll
+              for (int u = 0; u < RB; u++) a[u] = *reinterpret_cast<const f32x4u *>(q + u * HW);
+#pragma unroll
+              for (int u = 0; u < RB; u++) o[u] = f32x4{a[u][0], a[u][1], a[u][2], a[u][3]};
             } else {
-              const f32x4u a = *reinterpret_cast<const f32x4u *>(q);
-              const f32x3u b = *reinterpret_cast<const f32x3u *>(q + 4);
-              o = f32x4{a[0], a[2], b[0], b[2]};
+              f32x4u a[RB];
+              f32x3u b[RB];
+#pragma unroll
+              for (int u = 0; u < RB; u++) {
+                a[u] = *reinterpret_cast<const f32x4u *>(q + u * HW);
+                b[u] = *reinterpret_cast<const f32x3u *>(q + u * HW + 4);
+              }
+#pragma unroll
+              for (int u = 0; u < RB; u++) o[u] = f32x4{a[u][0], a[u][2], b[u][0], b[u][2]};
             }
-            *reinterpret_cast<f32x4 *>(dst + p) = o;
-            continue;
+            done = true;
+          }
+        }
+        if (!done) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int y = oj * st + y0, xx = oi * st + x0;
+            const bool in = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+#pragma unroll
+            for (int u = 0; u < RB; u++) o[u][e] = in ? src[u * HW + y * W + xx] : 0.f;
+            if (++oi == OW) { oi = 0; oj++; }
           }
         }
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int y = oj * st + y0, xx = oi * st + x0;
-          o[e] = ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) ? src[y * W + xx] : 0.f;
-          if (++oi == OW) { oi = 0; oj++; }
-        }
-        *reinterpret_cast<f32x4 *>(dst + p) = o;
+        for (int u = 0; u < RB; u++) *reinterpret_cast<f32x4 *>(dst + (int64_t)u * pitch + p) = o[u];
       }
       continue;
     }
     for (int p = blockIdx.x * NT + threadIdx.x; p < P; p += gridDim.x * NT) {
       const int oj = p / OW, oi = p - oj * OW;
       const int y = oj * st + y0, xx = oi * st + x0;
-      float v = 0.f;
-      if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = src[y * W + xx];
-      dst[p] = v;
+      const bool in = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+#pragma unroll
+      for (int u = 0; u < RB; u++) dst[(int64_t)u * pitch + p] = in ? src[u * HW + y * W + xx] : 0.f;
     }
   }
 }
 
 typedef void (*cols_fp_fn)(const float *, float *, Geo, int64_t, int, int);
-cols_fp_fn pick_cols_fp(bool vec4, int64_t stride) {
-  if (!vec4) return cols_fp<false, 0>;
-  return stride == 1 ? cols_fp<true, 1> : stride == 2 ? cols_fp<true, 2> : cols_fp<true, 0>;
+cols_fp_fn pick_cols_fp(bool vec4, int64_t stride, bool rb4) {
+  if (!vec4) return cols_fp<false, 0, 1>;
+  if (rb4) return stride == 1 ? cols_fp<true, 1, 4> : stride == 2 ? cols_fp<true, 2, 4> : cols_fp<true, 0, 4>;
+  return stride == 1 ? cols_fp<true, 1, 1> : stride == 2 ? cols_fp<true, 2, 1> : cols_fp<true, 0, 1>;
 }
 
 // colsb[n][(ob, tj, ti, o2)][(ih, iw)] = gout[n][ob*KB + o2][oj][oi] with kj = R-1-tj, ki = ti,
@@ -807,7 +830,8 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   const int start = bias == nullptr ? 3 : C % 64 != 0 ? 2 : 1;
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL(pick_cols_fp(P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, stride), gather_grid(P, nb * kp),
+    const bool v4 = P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, rb4 = v4 && g.CB % 4 == 0;   // (kp is a multiple of 32)
+    hipLaunchKernelGGL(pick_cols_fp(v4, stride, rb4), gather_grid(P, nb * kp / (rb4 ? 4 : 1)),
                        dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * kp, (int)kp, (int)Pp);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_start_launch_(out + n0 * K * P, Wm, cols, K, Pp, kp, kp, Pp, P, 0, 0, variant, nb, 0, kp * Pp,
@@ -936,7 +960,8 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
   }
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    hipLaunchKernelGGL(pick_cols_fp(P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, stride), gather_grid(P, nb * crs),
+    const bool v4 = P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, rb4 = v4 && g.CB % 4 == 0;   // (then crs is a multiple of 4)
+    hipLaunchKernelGGL(pick_cols_fp(v4, stride, rb4), gather_grid(P, nb * crs / (rb4 ? 4 : 1)),
                        dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs, (int)crs, (int)Pp);
     CHECK_LAUNCH(who);
     const float *ga = gout + n0 * K * P;
