@@ -290,11 +290,13 @@ __global__ __launch_bounds__(NT) void pack_w_bp_phase(const float *__restrict__ 
 
 // colsp[n][(ob, aj, ai, o2)][(yh, xh)] = gout[n][ob*KB + o2][yh + dj][xh + di] (0 outside), rows of ph.pitch floats
 // with a +0 tail.  One gathered row per blockIdx.y, threads along the phase's pixels.
+template <int RB>   // rows per block trip: RB consecutive output channels o2 of one tap (see cols_fp); needs KB % RB == 0
 __global__ __launch_bounds__(NT) void cols_bp_phase(const float *__restrict__ go, float *__restrict__ cols, Geo g, Phase ph,
                                                     int64_t nrows) {
   const int OH = (int)g.OH, OW = (int)g.OW, st = (int)g.stride, Wh = ph.Wh, HWp = ph.Hh * ph.Wh;
   const int krs = (int)g.K * ph.nj * ph.ni;
-  for (int64_t row = blockIdx.y; row < nrows; row += gridDim.y) {
+  const int64_t plane = (int64_t)OH * OW;
+  for (int64_t row = (int64_t)blockIdx.y * RB; row < nrows; row += (int64_t)gridDim.y * RB) {
     int kk = (int)(row % krs);
     const int64_t n = row / krs;
     const int o2 = kk % (int)g.KB; kk /= (int)g.KB;
@@ -303,28 +305,37 @@ __global__ __launch_bounds__(NT) void cols_bp_phase(const float *__restrict__ go
     const int ob = kk / ph.nj;
     const int kj = ph.kj0 + (ph.nj - 1 - aj) * st, ki = ph.ki0 + ai * st;
     const int dj = (ph.py + (int)g.pad - kj) / st, di = (ph.px + (int)g.pad - ki) / st;   // exact divisions
-    const float *src = go + (n * g.K + ob * g.KB + o2) * (int64_t)OH * OW;
+    const float *src = go + (n * g.K + ob * g.KB + o2) * plane;   // rows u = 0 .. RB-1: channels o2 + u
     float *dst = cols + row * ph.pitch;
     // four pixels per lane and one 16-byte store (the pitch is a multiple of 64); four pixels of one plane row that all
     // exist come from one 4-byte-aligned 16-byte load
     for (int pix = (blockIdx.x * NT + threadIdx.x) * 4; pix < ph.pitch; pix += gridDim.x * NT * 4) {
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      f32x4 o[RB];
+#pragma unroll
+      for (int u = 0; u < RB; u++) o[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (pix < HWp) {
         int yh = pix / Wh, xh = pix - yh * Wh;
         const int oj = yh + dj, oi = xh + di;
         if (xh + 3 < Wh && (unsigned)oj < (unsigned)OH && oi >= 0 && oi + 3 < OW) {
-          const f32x4u a = *reinterpret_cast<const f32x4u *>(src + oj * OW + oi);
-          o = f32x4{a[0], a[1], a[2], a[3]};
+          f32x4u a[RB];
+#pragma unroll
+          for (int u = 0; u < RB; u++) a[u] = *reinterpret_cast<const f32x4u *>(src + u * plane + oj * OW + oi);
+#pragma unroll
+          for (int u = 0; u < RB; u++) o[u] = f32x4{a[u][0], a[u][1], a[u][2], a[u][3]};
         } else {
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const int qj = yh + dj, qi = xh + di;
-            if (pix + e < HWp && (unsigned)qj < (unsigned)OH && (unsigned)qi < (unsigned)OW) o[e] = src[qj * OW + qi];
+            if (pix + e < HWp && (unsigned)qj < (unsigned)OH && (unsigned)qi < (unsigned)OW) {
+#pragma unroll
+              for (int u = 0; u < RB; u++) o[u][e] = src[u * plane + qj * OW + qi];
+            }
             if (++xh == Wh) { xh = 0; yh++; }
           }
         }
       }
-      *reinterpret_cast<f32x4 *>(dst + pix) = o;
+#pragma unroll
+      for (int u = 0; u < RB; u++) *reinterpret_cast<f32x4 *>(dst + (int64_t)u * ph.pitch + pix) = o[u];
     }
   }
 }
@@ -908,8 +919,9 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
         if (wph[p] == nullptr) continue;
         const Phase &ph = phs[p];
         const int64_t krs_p = K * ph.nj * ph.ni;
-        hipLaunchKernelGGL(cols_bp_phase, gather_grid(ph.pitch / 4, nb * krs_p), dim3(NT), 0, s, gout + n0 * K * P, gath, g,
-                           ph, nb * krs_p);
+        const bool rb4 = g.KB % 4 == 0;   // (then krs_p is a multiple of 4)
+        hipLaunchKernelGGL(rb4 ? cols_bp_phase<4> : cols_bp_phase<1>, gather_grid(ph.pitch / 4, nb * krs_p / (rb4 ? 4 : 1)),
+                           dim3(NT), 0, s, gout + n0 * K * P, gath, g, ph, nb * krs_p);
         CHECK_LAUNCH(who);
         rc = fpemu_gemm_chain_start_launch_(plane, wph[p], gath, C, ph.pitch, krs_p, krs_p, ph.pitch, ph.pitch, 0, 0,
                                             variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3, nullptr, 0, stream);
