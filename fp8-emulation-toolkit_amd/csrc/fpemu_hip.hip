@@ -35,7 +35,11 @@ using namespace fpemu;
 // fpemu_rows.hip: one launch of the per-row (per-channel / per-block) kernel
 extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype,
                                   int fmt, int rmode, float flt_max, int policy, uint64_t seed,
-                                  uint64_t offset, uint32_t *amax_out, int force_block, void *stream);
+                                  uint64_t offset, uint32_t *amax_out, int force_block, uint64_t col_base,
+                                  void *stream);
+// fpemu_rows.hip: row maxima only
+extern "C" int fpemu_rows_amax_launch_(const void *in, uint64_t rows, uint64_t cols, int dtype, uint32_t *amax_bits,
+                                       void *stream);
 
 namespace {
 
@@ -478,7 +482,10 @@ struct AmaxTable {
   uint32_t count;
 };
 
-template <int DT>
+// ATOMIC = false: word per WORKGROUP (partials[blockIdx.x]).  ATOMIC = true: word per TENSOR (partials[t], zeroed by the
+// caller), published with the conditional atomic of amax_kernel -- fpemu_amax_multi, whose words leave the device
+// (an all-reduce over the process group) before any cast reads them.
+template <int DT, bool ATOMIC>
 __global__ __launch_bounds__(kBlock) void amax_multi_kernel(AmaxTable tab, uint32_t *partials) {
   constexpr unsigned V = Storage<DT>::V;
   unsigned t = 0;
@@ -511,8 +518,18 @@ __global__ __launch_bounds__(kBlock) void amax_multi_kernel(AmaxTable tab, uint3
     for (int w = 1; w < kWavesPerBlock; w++) r = r > part[w] ? r : part[w];
     if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
     else if constexpr (DT == FPEMU_BF16) r = r << 16;
-    partials[blockIdx.x] = r;
+    if constexpr (ATOMIC) {
+      const uint32_t seen = __hip_atomic_load(partials + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (r > seen) __hip_atomic_fetch_max(partials + t, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      partials[blockIdx.x] = r;
+    }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void zero_words_kernel(uint32_t *w, uint64_t count) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < count) w[i] = 0u;
 }
 
 template <int kCastBlock>
@@ -561,7 +578,7 @@ __global__ __launch_bounds__(cast_block(RM, DT)) void cast_multi_scaled_kernel(M
   const unsigned first = t == 0u ? 0u : tab.blk_end[t - 1u];
   const unsigned pfirst = t == 0u ? 0u : ms.pend[t - 1u];
   const PartialsScale<cast_block(RM, DT)> src{ms.partials + pfirst, ms.pend[t] - pfirst, ms.flt_max, ms.clamp,
-                                              blockIdx.x == first ? ms.amax_words + t : nullptr};
+                                              (blockIdx.x == first && ms.amax_words != nullptr) ? ms.amax_words + t : nullptr};
   if constexpr (sr_by_slot(RM, DT))
     cast_blocks_sr<FMT, RM, DT>(tab.in[t], tab.out[t], tab.nsb[t], tab.n[t], src, seed, offset + t, 0, blockIdx.x - first,
                                 tab.blk_end[t] - first);
@@ -766,8 +783,9 @@ int fpemu_parse_mode(const char *mode, int *fmt, int *rmode) {
 
 int fpemu_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int rmode, float scale,
                uint64_t seed, uint64_t offset, uint64_t elem_base, void *stream) {
-  // the reference aborts the process on scale > FLT_MAX (cpp:772-776); report it instead
-  if (!(fabsf(scale) <= 3.402823466e+38f)) return fail(FPEMU_EINVAL, "fpemu_cast: invalid scale factor (inf or nan)");
+  // the reference aborts the process on `scale > FLT_MAX` (cpp:772-776, hip:1048-1052); report it instead.  That test
+  // is the whole check there: a NaN or -Inf scale runs and gives what the arithmetic gives, and so it does here.
+  if (scale > 3.402823466e+38f) return fail(FPEMU_EINVAL, "fpemu_cast: invalid scale factor (> FLT_MAX)");
   CastParams prm;
   prm.scale = scale;
   prm.rcp = (float)(1.0 / (double)scale);  // cpp:714
@@ -787,8 +805,7 @@ int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, i
                      uint64_t seed, uint64_t offset, void *stream) {
   if (count == 0) return FPEMU_OK;
   if (tensors == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast_multi: null tensor table");
-  if (!(fabsf(scale) <= 3.402823466e+38f))
-    return fail(FPEMU_EINVAL, "fpemu_cast_multi: invalid scale factor (inf or nan)");
+  if (scale > 3.402823466e+38f) return fail(FPEMU_EINVAL, "fpemu_cast_multi: invalid scale factor (> FLT_MAX)");
   if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_cast_multi: bad dtype id");
   const cast_multi_fn fn = dtype == FPEMU_F32   ? pick_cast_multi<FPEMU_F32>(fmt, rmode)
                            : dtype == FPEMU_F16 ? pick_cast_multi<FPEMU_F16>(fmt, rmode)
@@ -869,9 +886,9 @@ int fpemu_quantize_per_tensor_multi(const fpemu_tensor_t *tensors, uint64_t coun
       return bad(FPEMU_EALIGN, "buffer not aligned to its element size");
   }
   typedef void (*amax_multi_fn)(AmaxTable, uint32_t *);
-  const amax_multi_fn afn = dtype == FPEMU_F32   ? (amax_multi_fn)amax_multi_kernel<FPEMU_F32>
-                            : dtype == FPEMU_F16 ? (amax_multi_fn)amax_multi_kernel<FPEMU_F16>
-                                                 : (amax_multi_fn)amax_multi_kernel<FPEMU_BF16>;
+  const amax_multi_fn afn = dtype == FPEMU_F32   ? (amax_multi_fn)amax_multi_kernel<FPEMU_F32, false>
+                            : dtype == FPEMU_F16 ? (amax_multi_fn)amax_multi_kernel<FPEMU_F16, false>
+                                                 : (amax_multi_fn)amax_multi_kernel<FPEMU_BF16, false>;
   const uint64_t sb_elems = (uint64_t)ve * 64u * (unsigned)slots_per_wave(rmode, dtype);
   const unsigned kCastBlock = (unsigned)cast_block(rmode, dtype);
   uint32_t *partials = ws + count;
@@ -936,6 +953,128 @@ int fpemu_quantize_per_tensor_multi(const fpemu_tensor_t *tensors, uint64_t coun
   return FPEMU_OK;
 }
 
+int fpemu_amax_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, uint32_t *amax_words, void *stream) {
+  const char *who = "fpemu_amax_multi";
+  char msg[128];
+  auto bad = [&](int code, const char *what) {
+    snprintf(msg, sizeof(msg), "%s: %s", who, what);
+    return fail(code, msg);
+  };
+  if (count == 0) return FPEMU_OK;
+  if (tensors == nullptr || amax_words == nullptr) return bad(FPEMU_EINVAL, "null argument");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return bad(FPEMU_EINVAL, "bad dtype id");
+  const unsigned es = elem_size(dtype), ve = vec_elems(dtype);
+  for (uint64_t i = 0; i < count; i++) {
+    if (tensors[i].n != 0 && tensors[i].in == nullptr) return bad(FPEMU_EINVAL, "null buffer");
+    if ((uintptr_t)tensors[i].in % es) return bad(FPEMU_EALIGN, "buffer not aligned to its element size");
+  }
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, amax_words, count);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  typedef void (*amax_multi_fn)(AmaxTable, uint32_t *);
+  const amax_multi_fn afn = dtype == FPEMU_F32   ? (amax_multi_fn)amax_multi_kernel<FPEMU_F32, true>
+                            : dtype == FPEMU_F16 ? (amax_multi_fn)amax_multi_kernel<FPEMU_F16, true>
+                                                 : (amax_multi_fn)amax_multi_kernel<FPEMU_BF16, true>;
+  uint64_t i = 0;
+  while (i < count) {
+    AmaxTable at;
+    memset(&at, 0, sizeof(at));
+    uint64_t ablocks = 0;
+    unsigned k = 0;
+    const uint64_t first = i;
+    for (; i < count && k < (unsigned)kMultiTensors; i++, k++) {
+      const fpemu_tensor_t &t = tensors[i];
+      // workgroups: at least four vectors (or 16 elements) per thread, at most kAmaxMaxBlocks per tensor
+      const bool avec = ((uintptr_t)t.in % 16u) == 0;
+      const uint64_t nvec = avec ? t.n / ve : 0;
+      uint64_t ab = avec ? nvec / (4u * kBlock) : t.n / (16u * kBlock);
+      if (ab > (uint64_t)kAmaxMaxBlocks) ab = (uint64_t)kAmaxMaxBlocks;
+      if (ab < 1 && t.n != 0) ab = 1;
+      ablocks += ab;
+      at.in[k] = t.in;
+      at.n[k] = t.n;
+      at.nvec[k] = nvec;
+      at.blk_end[k] = (uint32_t)ablocks;
+    }
+    at.count = k;
+    if (ablocks != 0) {
+      hipLaunchKernelGGL(afn, dim3((unsigned)ablocks), dim3(kBlock), 0, (hipStream_t)stream, at, amax_words + first);
+      e = hipGetLastError();
+      if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+  }
+  return FPEMU_OK;
+}
+
+int fpemu_cast_multi_scaled(const fpemu_tensor_t *tensors, uint64_t count, int dtype, int fmt, int rmode,
+                            const uint32_t *amax_words, float flt_max, int clamp, uint64_t seed, uint64_t offset,
+                            void *stream) {
+  const char *who = "fpemu_cast_multi_scaled";
+  char msg[128];
+  auto bad = [&](int code, const char *what) {
+    snprintf(msg, sizeof(msg), "%s: %s", who, what);
+    return fail(code, msg);
+  };
+  if (count == 0) return FPEMU_OK;
+  if (tensors == nullptr || amax_words == nullptr) return bad(FPEMU_EINVAL, "null argument");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return bad(FPEMU_EINVAL, "bad dtype id");
+  const cast_multi_scaled_fn fn = dtype == FPEMU_F32   ? pick_cast_multi_scaled<FPEMU_F32>(fmt, rmode)
+                                  : dtype == FPEMU_F16 ? pick_cast_multi_scaled<FPEMU_F16>(fmt, rmode)
+                                                       : pick_cast_multi_scaled<FPEMU_BF16>(fmt, rmode);
+  if (fn == nullptr) return bad(FPEMU_EINVAL, "format / rounding-mode pair takes no scale or is not defined");
+  const unsigned es = elem_size(dtype);
+  for (uint64_t i = 0; i < count; i++) {  // validate everything before the first launch
+    if (tensors[i].n != 0 && (tensors[i].in == nullptr || tensors[i].out == nullptr)) return bad(FPEMU_EINVAL, "null buffer");
+    if (((uintptr_t)tensors[i].in % es) || ((uintptr_t)tensors[i].out % es))
+      return bad(FPEMU_EALIGN, "buffer not aligned to its element size");
+  }
+  const uint64_t sb_elems = (uint64_t)vec_elems(dtype) * 64u * (unsigned)slots_per_wave(rmode, dtype);
+  const unsigned kCastBlock = (unsigned)cast_block(rmode, dtype);
+  uint64_t i = 0;
+  while (i < count) {
+    MultiTable tab;
+    MultiScaleArgs ms;
+    memset(&tab, 0, sizeof(tab));
+    memset(&ms, 0, sizeof(ms));
+    uint64_t blocks = 0;
+    unsigned k = 0;
+    const uint64_t first = i;
+    for (; i < count && k < (unsigned)kMultiTensors; i++, k++) {
+      const fpemu_tensor_t &t = tensors[i];
+      const bool vec_ok = (((uintptr_t)t.in | (uintptr_t)t.out) % 16u) == 0;
+      const uint64_t nsb = vec_ok ? t.n / sb_elems : 0;
+      const uint64_t tail = t.n - nsb * sb_elems;
+      uint64_t b = superblock_groups(nsb, rmode, dtype);
+      const uint64_t tb = (tail + kCastBlock - 1) / kCastBlock;
+      if (b < tb) b = tb;
+      if (b > (uint64_t)max_blocks()) b = (uint64_t)max_blocks();
+      if (blocks + b > 0x7FFFFFFFull) {
+        if (k == 0) return bad(FPEMU_EINVAL, "tensor too large for one launch; use fpemu_cast_scaled");
+        break;
+      }
+      blocks += b;
+      tab.in[k] = t.in;
+      tab.out[k] = t.out;
+      tab.n[k] = t.n;
+      tab.nsb[k] = nsb;
+      tab.blk_end[k] = (uint32_t)blocks;
+      ms.pend[k] = k + 1u;  // one word per tensor: the word IS its maximum
+    }
+    tab.count = k;
+    if (blocks != 0) {
+      ms.partials = amax_words + first;
+      ms.amax_words = nullptr;  // nothing to publish: the caller holds the words already
+      ms.flt_max = flt_max;
+      ms.clamp = clamp ? 1 : 0;
+      hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kCastBlock), 0, (hipStream_t)stream, tab, ms, seed, offset + first);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    }
+  }
+  return FPEMU_OK;
+}
+
 int fpemu_forward(const void *in, void *out, int dtype, const char *mode, uint64_t size, float scale,
                   int block_norm, int block_size, uint64_t seed, uint64_t offset, void *stream) {
   int fmt = 0, rmode = 0;
@@ -945,8 +1084,7 @@ int fpemu_forward(const void *in, void *out, int dtype, const char *mode, uint64
     block_norm = 0;  // cpp:2020-2025
   // formats whose reference kernel has a block-norm branch; the others ignore the flag (cpp:1913-1957)
   if (block_norm && block_size > 0 && (fmt == E5M2 || fmt == E4M3 || fmt == E3M4 || fmt == E4M3_IEEE || fmt == FP4)) {
-    if (!(fabsf(scale) <= 3.402823466e+38f))
-      return fail(FPEMU_EINVAL, "fpemu_forward: invalid scale factor (inf or nan)");
+    if (scale > 3.402823466e+38f) return fail(FPEMU_EINVAL, "fpemu_forward: invalid scale factor (> FLT_MAX)");
     return fpemu_quantize_blocks(in, out, size, (uint64_t)block_size, dtype, fmt, rmode, seed, offset, stream);
   }
   return fpemu_cast(in, out, size, dtype, fmt, rmode, scale, seed, offset, 0, stream);
@@ -1035,7 +1173,7 @@ int fpemu_quantize_per_tensor(const void *in, void *out, uint64_t n, int dtype, 
   if (dtype >= FPEMU_F32 && dtype <= FPEMU_BF16 && n <= kSmallVectors * vec_elems(dtype) && in != nullptr && out != nullptr &&
       ((uintptr_t)in % elem_size(dtype)) == 0 && ((uintptr_t)out % elem_size(dtype)) == 0) {
     const int rc1 = fpemu_rows_launch_(in, out, 1, n, dtype, fmt, rmode, flt_max, clamp ? 1 : 0, seed, offset,
-                                       amax_ws, /*force_block=*/1, stream);
+                                       amax_ws, /*force_block=*/1, /*col_base=*/0, stream);
     if (rc1 != kNoRowsKernel) return rc1;  // formats without a scale fall through to the flat path
   }
   hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax_ws);
@@ -1131,7 +1269,7 @@ int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols,
   if (((uintptr_t)in % es) || ((uintptr_t)out % es))
     return fail(FPEMU_EALIGN, "fpemu_quantize_rows: buffer not aligned to its element size");
   const int rc = fpemu_rows_launch_(in, out, rows, cols, dtype, fmt, rmode, flt_max, clamp ? 1 : 0, seed, offset,
-                                    nullptr, 0, stream);
+                                    nullptr, 0, 0, stream);
   if (rc == kNoRowsKernel)
     return fail(FPEMU_EINVAL, "fpemu_quantize_rows: format / rounding-mode pair takes no scale or is not defined");
   return rc;
@@ -1148,9 +1286,44 @@ int fpemu_cast_rows_scaled(const void *in, void *out, uint64_t rows, uint64_t co
   if (((uintptr_t)in % es) || ((uintptr_t)out % es) || ((uintptr_t)scales % 4u))
     return fail(FPEMU_EALIGN, "fpemu_cast_rows_scaled: buffer not aligned to its element size");
   const int rc = fpemu_rows_launch_(in, out, rows, cols, dtype, fmt, rmode, 0.f, /*scale given*/ 3, seed, offset,
-                                    const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(scales)), 0, stream);
+                                    const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(scales)), 0, 0, stream);
   if (rc == kNoRowsKernel)
     return fail(FPEMU_EINVAL, "fpemu_cast_rows_scaled: format / rounding-mode pair takes no scale or is not defined");
+  return rc;
+}
+
+int fpemu_amax_rows(const void *in, uint64_t rows, uint64_t cols, int dtype, uint32_t *amax_bits, void *stream) {
+  if (rows == 0) return FPEMU_OK;
+  if (amax_bits == nullptr) return fail(FPEMU_EINVAL, "fpemu_amax_rows: null amax vector");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_amax_rows: bad dtype id");
+  if (rows > 0x7FFFFFFFull) return fail(FPEMU_EINVAL, "fpemu_amax_rows: more than 2^31-1 rows");
+  if (cols == 0) {  // empty rows: the maximum of nothing is the zero word
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, amax_bits, rows);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return FPEMU_OK;
+  }
+  if (in == nullptr) return fail(FPEMU_EINVAL, "fpemu_amax_rows: null buffer");
+  if ((uintptr_t)in % elem_size(dtype)) return fail(FPEMU_EALIGN, "fpemu_amax_rows: buffer not aligned to its element size");
+  return fpemu_rows_amax_launch_(in, rows, cols, dtype, amax_bits, stream);
+}
+
+int fpemu_cast_rows_amax(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt, int rmode,
+                         const uint32_t *amax_bits, float flt_max, int clamp, uint64_t seed, uint64_t offset,
+                         uint64_t col_base, void *stream) {
+  if (rows == 0 || cols == 0) return FPEMU_OK;
+  if (in == nullptr || out == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast_rows_amax: null buffer");
+  if (amax_bits == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast_rows_amax: null amax vector");
+  if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_cast_rows_amax: bad dtype id");
+  if (rows > 0x7FFFFFFFull) return fail(FPEMU_EINVAL, "fpemu_cast_rows_amax: more than 2^31-1 rows");
+  const unsigned es = elem_size(dtype);
+  if (((uintptr_t)in % es) || ((uintptr_t)out % es) || ((uintptr_t)amax_bits % 4u))
+    return fail(FPEMU_EALIGN, "fpemu_cast_rows_amax: buffer not aligned to its element size");
+  const int rc = fpemu_rows_launch_(in, out, rows, cols, dtype, fmt, rmode, flt_max, /*amax words given*/ clamp ? 5 : 4, seed,
+                                    offset, const_cast<uint32_t *>(amax_bits), 0, col_base, stream);
+  if (rc == kNoRowsKernel)
+    return fail(FPEMU_EINVAL, "fpemu_cast_rows_amax: format / rounding-mode pair takes no scale or is not defined");
   return rc;
 }
 
@@ -1169,7 +1342,7 @@ int fpemu_quantize_blocks(const void *in, void *out, uint64_t n, uint64_t block_
   if (((uintptr_t)in % es) || ((uintptr_t)out % es))
     return fail(FPEMU_EALIGN, "fpemu_quantize_blocks: buffer not aligned to its element size");
   const int rc = fpemu_rows_launch_(in, out, rows, block_size, dtype, fmt, rmode, 0.f, /*block norm*/ 2, seed,
-                                    offset, nullptr, 0, stream);
+                                    offset, nullptr, 0, 0, stream);
   if (rc == kNoRowsKernel)
     return fail(FPEMU_EINVAL, "fpemu_quantize_blocks: format / rounding-mode pair not defined");
   return rc;

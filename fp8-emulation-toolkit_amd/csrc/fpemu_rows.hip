@@ -32,7 +32,14 @@ using namespace fpemu;
 
 namespace {
 
-enum { kRowsNoClamp = 0, kRowsClamp = 1, kRowsBlockNorm = 2, kRowsGiven = 3 };
+// kRowsAmaxNoClamp / kRowsAmaxClamp: the reduction is skipped as for kRowsGiven, but aux[r] holds row r's AMAX WORD
+// (fpemu_amax_rows, possibly all-reduced over a process group) and the scale is derived from it as usual.
+enum { kRowsNoClamp = 0, kRowsClamp = 1, kRowsBlockNorm = 2, kRowsGiven = 3, kRowsAmaxNoClamp = 4, kRowsAmaxClamp = 5 };
+
+// scale of a row whose reduction is skipped (policy >= kRowsGiven)
+__device__ __forceinline__ float row_scale_given(const uint32_t *aux, uint64_t row, float flt_max, int policy) {
+  return policy == kRowsGiven ? u2f(aux[row]) : scale_from_amax(aux[row], flt_max, policy == kRowsAmaxClamp);
+}
 constexpr uint64_t kWaveRowCols = 1024;
 constexpr uint64_t kLaneRowCols = 16;
 
@@ -52,8 +59,10 @@ template <int DT> __device__ __forceinline__ uint32_t drop_nan(uint32_t w) {
 template <int FMT, int RM, int DT, bool VEC, int TEAM>
 __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out_, uint64_t rows,
                                                       uint64_t cols, float flt_max, int policy,
-                                                      uint64_t seed, uint64_t offset, uint32_t *aux) {
-  // aux: kRowsGiven reads row r's scale (float bits) from aux[r]; otherwise, when not null, aux[r] receives the amax word
+                                                      uint64_t seed, uint64_t offset, uint32_t *aux,
+                                                      uint64_t col_base) {
+  // aux: kRowsGiven reads row r's scale (float bits) from aux[r], kRowsAmax* its amax word; otherwise, when not
+  // null, aux[r] receives the amax word.  col_base: index of column 0 in the row's noise stream (a row SEGMENT).
   constexpr unsigned V = Storage<DT>::V;
   constexpr bool SR = (RM == STOCHASTIC);
   static_assert(TEAM == 1 || TEAM == 64 || TEAM == kBlock, "team = lane, wave or block");
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out
   u32x4 *vout = reinterpret_cast<u32x4 *>(eout);
   const uint64_t nvec = (VEC && TEAM != 1) ? cols / V : 0;  // a lone lane walks its short row by element
   const bool bn = (policy == kRowsBlockNorm);
-  const bool given = (policy == kRowsGiven);  // uniform over the launch
+  const bool given = (policy >= kRowsGiven);  // uniform over the launch
 
   uint32_t m = 0u;
   for (uint64_t i = t; i < (given ? 0u : nvec); i += TS) {
@@ -99,19 +108,19 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out
   if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
   else if constexpr (DT == FPEMU_BF16) r = r << 16;
   if (aux != nullptr && !given && t == 0) aux[row] = r;
-  const float scale = given ? u2f(aux[row])
+  const float scale = given ? row_scale_given(aux, row, flt_max, policy)
                       : bn  ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
   const float rcp = scale_reciprocal(scale);
   const uint64_t roff = offset + row;
 
   for (uint64_t i = t; i < nvec; i += TS) {
-    const u32x4 o = cast_vector<FMT, RM, DT>(vin[i], scale, rcp, ElemNoise<FMT, V>{seed, roff, i * V});
+    const u32x4 o = cast_vector<FMT, RM, DT>(vin[i], scale, rcp, ElemNoise<FMT, V>{seed, roff, col_base + i * V});
     vout[i] = o;
   }
 #pragma clang loop vectorize(disable) interleave(disable)
   for (uint64_t e = nvec * V + t; e < cols; e += TS) {
     uint32_t rnd = 0u;
-    if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, e);
+    if constexpr (SR) rnd = rand_bits_elem<FMT, V>(seed, roff, col_base + e);
     if constexpr (DT == FPEMU_F32) eout[e] = cast_one<FMT, RM>(ein[e], scale, rcp, rnd);
     else eout[e] = (elem_t)store_elem16<DT>(cast_one<FMT, RM>(load_elem16<DT>(ein[e]), scale, rcp, rnd));
   }
@@ -172,13 +181,14 @@ template <int DT> __device__ __forceinline__ uint32_t absmax16_vector(const u32x
 template <int FMT, int RM, int DT, int NV, int BLOCK, int R = 1>
 __global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *out_, uint64_t rows,
                                                          uint32_t nv, uint32_t lg, float flt_max, int policy,
-                                                         uint64_t seed, uint64_t offset, uint32_t *aux) {
+                                                         uint64_t seed, uint64_t offset, uint32_t *aux,
+                                                         uint64_t col_base) {
   constexpr unsigned V = Storage<DT>::V;
   constexpr int kWaves = BLOCK / 64;
   const unsigned G = 1u << lg;
   const unsigned t = threadIdx.x & (G - 1u);
   const bool bn = (policy == kRowsBlockNorm);
-  const bool given = (policy == kRowsGiven);  // uniform over the launch: scalar branches
+  const bool given = (policy >= kRowsGiven);  // uniform over the launch: scalar branches
 
   uint64_t row[R];
   bool live[R];
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *
   float scale[R];
   if (given) {
 #pragma unroll
-    for (int q = 0; q < R; q++) scale[q] = u2f(aux[live[q] ? row[q] : 0]);
+    for (int q = 0; q < R; q++) scale[q] = row_scale_given(aux, live[q] ? row[q] : 0, flt_max, policy);
   } else {
     uint32_t m[R];
 #pragma unroll
@@ -253,14 +263,14 @@ __global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       const uint32_t i = (uint32_t)k * G + t;
-      const u32x4 o = cast_vector<FMT, RM, DT>(v[q][k], scale[q], rcp, ElemNoise<FMT, V>{seed, roff, (uint64_t)i * V});
+      const u32x4 o = cast_vector<FMT, RM, DT>(v[q][k], scale[q], rcp, ElemNoise<FMT, V>{seed, roff, col_base + (uint64_t)i * V});
       if (live[q] && i < nv) store_stream(&vout[i], o);
     }
   }
 }
 
 typedef void (*rows_reg_fn)(const void *, void *, uint64_t, uint32_t, uint32_t, float, int, uint64_t, uint64_t,
-                            uint32_t *);
+                            uint32_t *, uint64_t);
 
 template <int DT, int NV, int BLOCK = kBlock, int RPL = 1> rows_reg_fn pick_rows_reg(int fmt, int rm) {
 #define FPEMU_CASE(F, R) \
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void rows_subvec_kernel(const void *in_, vo
     if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
     else if constexpr (DT == FPEMU_BF16) r = r << 16;
     const uint64_t g = idx * V + e;  // global element
-    const float scale = policy == kRowsGiven ? u2f(aux[g >> lgbs])
+    const float scale = policy >= kRowsGiven ? row_scale_given(aux, g >> lgbs, flt_max, policy)
                         : bn                 ? blocknorm_scale<FMT>(r) : scale_from_amax(r, flt_max, policy == kRowsClamp);
     const float rcp = scale_reciprocal(scale);
     uint32_t rnd = 0u;
@@ -402,7 +412,7 @@ template <int DT> rows_subvec_fn pick_rows_subvec(int fmt, int rm) {
   return nullptr;
 }
 
-typedef void (*rows_fn)(const void *, void *, uint64_t, uint64_t, float, int, uint64_t, uint64_t, uint32_t *);
+typedef void (*rows_fn)(const void *, void *, uint64_t, uint64_t, float, int, uint64_t, uint64_t, uint32_t *, uint64_t);
 
 template <int DT, bool VEC, int TEAM> rows_fn pick_rows(int fmt, int rm) {
 #define FPEMU_CASE(F, R) \
@@ -425,19 +435,103 @@ template <int DT> rows_fn pick_rows_dt(bool vec, int team, int fmt, int rm) {
   return vec ? pick_rows<DT, true, kBlock>(fmt, rm) : pick_rows<DT, false, kBlock>(fmt, rm);
 }
 
+// Row maxima only: amax_bits[r] = fp32 bit pattern of max |row r| (torch.max semantics: a NaN wins).  The first half of
+// a per-channel quantisation whose rows are spread over several GPUs: every rank reduces its row SEGMENTS, the
+// vector of words is all-reduced (MAX) over the process group, and the cast reads the words back (kRowsAmax*).
+// Same teams as rows_kernel; read-once stream (non-temporal loads).
+template <int DT, bool VEC, int TEAM>
+__global__ __launch_bounds__(kBlock) void rows_amax_kernel(const void *in_, uint64_t rows, uint64_t cols,
+                                                           uint32_t *amax_bits) {
+  constexpr unsigned V = Storage<DT>::V;
+  constexpr unsigned TS = (unsigned)TEAM;
+  using elem_t = typename Storage<DT>::elem;
+  const unsigned t = TEAM == 1 ? 0u : TEAM == 64 ? (threadIdx.x & 63u) : threadIdx.x;
+  const uint64_t row = TEAM == 1    ? (uint64_t)blockIdx.x * kBlock + threadIdx.x
+                       : TEAM == 64 ? (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)
+                                    : (uint64_t)blockIdx.x;
+  if (TEAM != kBlock && row >= rows) return;  // only the block team has a barrier below
+  const elem_t *ein = reinterpret_cast<const elem_t *>(in_) + row * cols;
+  const u32x4 *vin = reinterpret_cast<const u32x4 *>(ein);
+  const uint64_t nvec = (VEC && TEAM != 1) ? cols / V : 0;
+  uint32_t m = 0u;
+#pragma unroll 4
+  for (uint64_t i = t; i < nvec; i += TS) {
+    const u32x4 v = __builtin_nontemporal_load(&vin[i]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) m = absmax_word<DT>(m, v[j]);
+  }
+#pragma clang loop vectorize(disable) interleave(disable)
+  for (uint64_t e = nvec * V + t; e < cols; e += TS) {
+    uint32_t w;
+    if constexpr (DT == FPEMU_F32) w = f2u(ein[e]);
+    else w = (uint32_t)ein[e];
+    m = absmax_word<DT>(m, w);
+  }
+  uint32_t r = m;
+  if constexpr (TEAM != 1) r = wave_max_u32(m);
+  if constexpr (TEAM == kBlock) {
+    __shared__ uint32_t part[kWavesPerBlock];
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = r;
+    __syncthreads();
+    r = part[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; w++) r = r > part[w] ? r : part[w];
+  }
+  if constexpr (DT == FPEMU_F16) r = f2u(h_to_f32(r));
+  else if constexpr (DT == FPEMU_BF16) r = r << 16;
+  if (t == 0) amax_bits[row] = r;
+}
+
+typedef void (*rows_amax_fn)(const void *, uint64_t, uint64_t, uint32_t *);
+
+template <int DT> rows_amax_fn pick_rows_amax(bool vec, int team) {
+  if (team == 1) return rows_amax_kernel<DT, false, 1>;
+  if (team == 64) return vec ? rows_amax_kernel<DT, true, 64> : rows_amax_kernel<DT, false, 64>;
+  return vec ? rows_amax_kernel<DT, true, kBlock> : rows_amax_kernel<DT, false, kBlock>;
+}
+
 }  // namespace
+
+// Internal to the library (declared in fpemu_hip.hip): one launch of rows_amax_kernel; arguments validated by the caller.
+extern "C" int fpemu_rows_amax_launch_(const void *in, uint64_t rows, uint64_t cols, int dtype, uint32_t *amax_bits,
+                                       void *stream) {
+  const int team = cols > kWaveRowCols ? kBlock : cols > kLaneRowCols ? 64 : 1;
+  const bool vec = ((uintptr_t)in % 16u) == 0 && (cols % vec_elems(dtype)) == 0;
+  rows_amax_fn fn = dtype == FPEMU_F32 ? pick_rows_amax<FPEMU_F32>(vec, team)
+                  : dtype == FPEMU_F16 ? pick_rows_amax<FPEMU_F16>(vec, team)
+                  : dtype == FPEMU_BF16 ? pick_rows_amax<FPEMU_BF16>(vec, team) : nullptr;
+  if (fn == nullptr) {
+    fpemu_set_error_("fpemu_amax_rows: bad dtype id");
+    return FPEMU_EINVAL;
+  }
+  const uint64_t per_block = team == 1 ? (uint64_t)kBlock : team == 64 ? (uint64_t)kWavesPerBlock : 1u;
+  const uint64_t blocks = (rows + per_block - 1) / per_block;
+  if (blocks > 0x7FFFFFFFull) {
+    fpemu_set_error_("fpemu_amax_rows: more than 2^31-1 workgroups");
+    return FPEMU_EINVAL;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, in, rows, cols, amax_bits);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fpemu_set_error_(hipGetErrorString(e));
+    return (int)e;
+  }
+  return FPEMU_OK;
+}
 
 // Internal to the library (declared in fpemu_hip.hip).  Arguments are validated by the callers except
 // for what depends on the kernel choice.  force_block: always one block per row (the per-tensor small
 // path: one row of up to 32 Ki elements).  amax_out: policy 3 (kRowsGiven) READS one float scale per row from it;
-// the other policies write the row's amax word there when it is not null.
+// policies 4 / 5 (kRowsAmax*) READ one amax word per row; the other policies write the row's amax word there when
+// it is not null.  col_base: index of column 0 in each row's noise stream (row segments of a sharded tensor).
 extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype,
                                   int fmt, int rmode, float flt_max, int policy, uint64_t seed,
-                                  uint64_t offset, uint32_t *amax_out, int force_block, void *stream) {
+                                  uint64_t offset, uint32_t *amax_out, int force_block, uint64_t col_base,
+                                  void *stream) {
   const unsigned ve = vec_elems(dtype);
   // blocks shorter than a vector: the flat cast's geometry with a scale per element
-  if (cols < ve && (ve % cols) == 0 && (amax_out == nullptr || policy == kRowsGiven) && (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 &&
-      ((rows * cols) % ve) == 0) {
+  if (cols < ve && (ve % cols) == 0 && (amax_out == nullptr || policy >= kRowsGiven) && col_base == 0 &&
+      (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && ((rows * cols) % ve) == 0) {
     rows_subvec_fn sf = dtype == FPEMU_F32 ? pick_rows_subvec<FPEMU_F32>(fmt, rmode)
                       : dtype == FPEMU_F16 ? pick_rows_subvec<FPEMU_F16>(fmt, rmode)
                       : dtype == FPEMU_BF16 ? pick_rows_subvec<FPEMU_BF16>(fmt, rmode) : nullptr;
@@ -478,7 +572,7 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
       return FPEMU_EINVAL;
     }
     hipLaunchKernelGGL(rf, dim3((unsigned)nblk), dim3(kBlock), 0, (hipStream_t)stream, in, out, rows, nv, lg,
-                       flt_max, policy, seed, offset, amax_out);
+                       flt_max, policy, seed, offset, amax_out, col_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
       fpemu_set_error_(hipGetErrorString(e));
@@ -505,7 +599,7 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
         return FPEMU_EINVAL;
       }
       hipLaunchKernelGGL(rf, dim3((unsigned)rows), dim3(block), 0, (hipStream_t)stream, in, out, rows, nv,
-                         mid ? 9u : 10u, flt_max, policy, seed, offset, amax_out);
+                         mid ? 9u : 10u, flt_max, policy, seed, offset, amax_out, col_base);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) {
         fpemu_set_error_(hipGetErrorString(e));
@@ -530,7 +624,7 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
     return FPEMU_EINVAL;
   }
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, in, out, rows, cols,
-                     flt_max, policy, seed, offset, amax_out);
+                     flt_max, policy, seed, offset, amax_out, col_base);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fpemu_set_error_(hipGetErrorString(e));

@@ -84,9 +84,13 @@ at::Tensor quantize_per_tensor_impl(const at::Tensor &input, bool inplace, int64
   at::Tensor dst = inplace ? src : at::empty_like(src);
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(src.device());
   const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(src.get_device());
-  at::Tensor ws = (ws_opt.has_value() && ws_opt->defined()) ? *ws_opt : stream_workspace(src, stream);
-  TORCH_CHECK(ws.is_cuda() && ws.scalar_type() == at::kInt && ws.numel() >= 1 && ws.get_device() == src.get_device(),
-              "fpemu: workspace must be an int32 tensor on the input's device");
+  // an override workspace that lives on another device is ignored, as _binding._stream_workspace does (a graph
+  // captured for one GPU must not stop tensors on a second one from being quantised)
+  const bool use_override = ws_opt.has_value() && ws_opt->defined() && ws_opt->is_cuda() &&
+                            ws_opt->get_device() == src.get_device();
+  at::Tensor ws = use_override ? *ws_opt : stream_workspace(src, stream);
+  TORCH_CHECK(ws.is_cuda() && ws.scalar_type() == at::kInt && ws.numel() >= 1 && ws.is_contiguous(),
+              "fpemu: workspace must be a contiguous int32 tensor");
   check(fpemu_quantize_per_tensor_ws(src.data_ptr(), dst.data_ptr(), (uint64_t)src.numel(), dtype_id(src), (int)fmt,
                                      (int)rmode, (float)flt_max, clamp ? 1 : 0, (uint32_t *)ws.data_ptr(),
                                      (uint64_t)ws.numel(), seed, offset, (void *)stream.stream()));

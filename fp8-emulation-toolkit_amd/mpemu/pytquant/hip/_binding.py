@@ -89,7 +89,15 @@ def lib():
         L.fpemu_cast_multi.argtypes = [vp, u64, i32, i32, i32, f32, u64, u64, vp]
         L.fpemu_quantize_per_tensor_multi.restype = i32
         L.fpemu_quantize_per_tensor_multi.argtypes = [vp, u64, i32, i32, i32, f32, i32, vp, u64, u64, u64, vp]
-        if L.fpemu_abi_version() != 8:
+        L.fpemu_amax_multi.restype = i32
+        L.fpemu_amax_multi.argtypes = [vp, u64, i32, vp, vp]
+        L.fpemu_cast_multi_scaled.restype = i32
+        L.fpemu_cast_multi_scaled.argtypes = [vp, u64, i32, i32, i32, vp, f32, i32, u64, u64, vp]
+        L.fpemu_amax_rows.restype = i32
+        L.fpemu_amax_rows.argtypes = [vp, u64, u64, i32, vp, vp]
+        L.fpemu_cast_rows_amax.restype = i32
+        L.fpemu_cast_rows_amax.argtypes = [vp, vp, u64, u64, i32, i32, i32, vp, f32, i32, u64, u64, u64, vp]
+        if L.fpemu_abi_version() != 9:
             raise ImportError("libfpemu_hip.so: ABI version mismatch")
         _lib = L
     return _lib
@@ -249,6 +257,7 @@ def _next_offset(rmode):
 
 
 next_offset = _next_offset
+take_offsets = _take_offsets
 
 
 def cast_(src, dst, fmt, rmode, scale=1.0, seed=None, offset=None, elem_base=0):
@@ -332,6 +341,92 @@ def quantize_per_tensor_multi_(srcs, fmt, rmode, flt_max, dsts=None, clamp=True,
     return dsts, ws
 
 
+def _tensor_table(srcs, dsts, who):
+    first = srcs[0]
+    tab = (_TensorEntry * len(srcs))()
+    for i, (a, b) in enumerate(zip(srcs, dsts)):
+        _require_device(a)
+        _require_device(b, "output")
+        if a.dtype != first.dtype or a.device != first.device or b.dtype != a.dtype or b.device != a.device:
+            raise ValueError("fpemu: %s needs tensors of one dtype on one device" % who)
+        if b.numel() != a.numel():
+            raise ValueError("fpemu: input/output mismatch")
+        tab[i].inp, tab[i].out, tab[i].n = a.data_ptr(), b.data_ptr(), a.numel()
+    return tab
+
+
+def _require_words(words, like, count, what="amax words"):
+    if (not torch.is_tensor(words) or words.device != like.device or words.dtype != torch.int32
+            or not words.is_contiguous() or words.numel() < count):
+        raise ValueError("fpemu: %s must be a contiguous int32 tensor of at least %d element(s) on %s"
+                         % (what, count, like.device))
+
+
+def amax_multi_(srcs, words):
+    """words[i] (int32, device) <- bit pattern of max|srcs[i]| for a list of contiguous tensors of one dtype on one
+    device: the first half of quantize_per_tensor_multi_ for SHARDED tensors -- all-reduce `words` over the process
+    group, then cast_multi_scaled_."""
+    srcs = list(srcs)
+    if not srcs:
+        return words
+    _require_words(words, srcs[0], len(srcs))
+    tab = _tensor_table(srcs, srcs, "amax_multi_")
+    with _range("fpemu::amax_multi"), _on_device(srcs[0]):
+        _check(lib().fpemu_amax_multi(ctypes.cast(tab, ctypes.c_void_p), len(srcs), _dtype_id(srcs[0]),
+                                      words.data_ptr(), _stream(srcs[0])))
+    return words
+
+
+def cast_multi_scaled_(srcs, fmt, rmode, words, flt_max, dsts=None, clamp=True, seed=None, offset=None):
+    """Tensor i is cast with the scale derived on the device from words[i] (its amax bit pattern), in place unless
+    `dsts` is given; one launch per 32 tensors.  Tensor i draws as call `offset + i`."""
+    srcs = list(srcs)
+    dsts = srcs if dsts is None else list(dsts)
+    if len(dsts) != len(srcs):
+        raise ValueError("fpemu: input/output lists differ in length")
+    if not srcs:
+        return dsts
+    _require_words(words, srcs[0], len(srcs))
+    tab = _tensor_table(srcs, dsts, "cast_multi_scaled_")
+    if offset is None:
+        offset = _take_offsets(len(srcs)) if rmode == STOCHASTIC else 0
+    with _range("fpemu::cast_multi_scaled"), _on_device(srcs[0]):
+        _check(lib().fpemu_cast_multi_scaled(ctypes.cast(tab, ctypes.c_void_p), len(srcs), _dtype_id(srcs[0]), fmt, rmode,
+                                             words.data_ptr(), float(flt_max), int(bool(clamp)),
+                                             _seed if seed is None else seed, offset, _stream(srcs[0])))
+    return dsts
+
+
+def amax_rows_(src, rows, words):
+    """words[r] (int32, device) <- bit pattern of max|row r| of the contiguous buffer viewed as [rows, numel/rows]."""
+    _require_device(src)
+    n = src.numel()
+    if rows <= 0 or n % rows:
+        raise ValueError("fpemu: %d elements do not split into %d rows" % (n, rows))
+    _require_words(words, src, rows)
+    with _range("fpemu::amax_rows"), _on_device(src):
+        _check(lib().fpemu_amax_rows(src.data_ptr(), rows, n // rows, _dtype_id(src), words.data_ptr(), _stream(src)))
+    return words
+
+
+def cast_rows_amax_(src, dst, rows, fmt, rmode, words, flt_max, clamp=True, seed=None, offset=None, col_base=0):
+    """Row r of the [rows, numel/rows] view is cast with the scale derived on the device from words[r]; row r draws
+    as call `offset + r`, its element c as element `col_base + c` (row segments of a sharded tensor)."""
+    _require_device(src)
+    _require_device(dst, "output")
+    n = src.numel()
+    if rows <= 0 or n % rows:
+        raise ValueError("fpemu: %d elements do not split into %d rows" % (n, rows))
+    _require_words(words, src, rows)
+    if offset is None:
+        offset = _take_offsets(rows) if rmode == STOCHASTIC else 0
+    with _range("fpemu::cast_rows_amax"), _on_device(src):
+        _check(lib().fpemu_cast_rows_amax(src.data_ptr(), dst.data_ptr(), rows, n // rows, _dtype_id(src), fmt, rmode,
+                                          words.data_ptr(), float(flt_max), int(bool(clamp)),
+                                          _seed if seed is None else seed, offset, int(col_base), _stream(src)))
+    return dst
+
+
 def amax_(src, amax_bits):
     """amax_bits (int32[1], same device, zeroed by the caller) <- max(amax_bits, bits(max|src|))."""
     _require_device(src)
@@ -375,7 +470,7 @@ def cast_device_scale_(src, dst, fmt, rmode, scale, seed=None, offset=None, elem
     return dst
 
 
-def cast_rows_scaled_(src, dst, rows, fmt, rmode, scales):
+def cast_rows_scaled_(src, dst, rows, fmt, rmode, scales, offset=None):
     """Cast of a contiguous buffer viewed as [rows, numel/rows] with scales[r] (float32, device) for row r, one
     launch; equals a loop of per-row casts with consecutive call offsets."""
     _require_device(src)
@@ -384,7 +479,7 @@ def cast_rows_scaled_(src, dst, rows, fmt, rmode, scales):
     if rows <= 0 or n % rows:
         raise ValueError("fpemu: %d elements do not split into %d rows" % (n, rows))
     _require_scales(scales, src, rows)
-    off = _take_offsets(rows) if rmode == STOCHASTIC else _offset
+    off = offset if offset is not None else (_take_offsets(rows) if rmode == STOCHASTIC else 0)
     with _range("fpemu::cast_rows_scaled"), _on_device(src):
         _check(lib().fpemu_cast_rows_scaled(src.data_ptr(), dst.data_ptr(), rows, n // rows, _dtype_id(src), fmt,
                                             rmode, scales.data_ptr(), _seed, off, _stream(src)))
@@ -454,7 +549,7 @@ def quantize_per_tensor_(src, dst, fmt, rmode, flt_max, amax_ws=None, clamp=True
     return dst
 
 
-def quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=True):
+def quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=True, offset=None):
     """Per-row amax -> scale -> cast of a contiguous buffer viewed as [rows, numel/rows], one launch
     (the per-channel / fine-grained policies of qutils.py:289-337)."""
     _require_device(src)
@@ -463,7 +558,7 @@ def quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=True):
     if rows <= 0 or n % rows:
         raise ValueError("fpemu: %d elements do not split into %d rows" % (n, rows))
     # one call offset per row, as a loop of per-row casts would consume
-    off = _take_offsets(rows) if rmode == STOCHASTIC else _offset
+    off = offset if offset is not None else (_take_offsets(rows) if rmode == STOCHASTIC else 0)
     with _range("fpemu::quantize_rows"), _on_device(src):
         _check(lib().fpemu_quantize_rows(src.data_ptr(), dst.data_ptr(), rows, n // rows, _dtype_id(src),
                                          fmt, rmode, float(flt_max), int(bool(clamp)), _seed, off,
@@ -482,7 +577,7 @@ def quantize_blocks_(src, dst, block_size, fmt, rmode):
     n = src.numel()
     if block_size <= 0 or n % block_size:
         raise ValueError("fpemu: %d elements do not split into blocks of %d" % (n, block_size))
-    off = _take_offsets(n // block_size) if rmode == STOCHASTIC else _offset
+    off = _take_offsets(n // block_size) if rmode == STOCHASTIC else 0
     with _range("fpemu::quantize_blocks"), _on_device(src):
         _check(lib().fpemu_quantize_blocks(src.data_ptr(), dst.data_ptr(), n, block_size, _dtype_id(src), fmt,
                                            rmode, _seed, off, _stream(src)))

@@ -17,7 +17,11 @@ With `set_amax_process_group(group)` a per-tensor "max" cast treats the tensor a
 of a larger tensor: the local amax word is all-reduced (MAX) over the group before the cast,
 so every rank derives the same scale, and the stochastic noise is indexed by the shard's GLOBAL
 position (`elem_base`), so the sharded result is the single-device result bit for bit
-(DESIGN.md "Multi-GPU").
+(DESIGN.md "Multi-GPU").  Per-channel / fine-grained "max" scaling under a group needs to know how
+the rows lie across the ranks (`layout`): "channels" -- dim 0 is sharded, every rank holds whole
+rows, no exchange; "flat" -- the tensor is this rank's contiguous piece of the flattened logical
+[rows, cols] tensor, rows may straddle ranks: one all-reduce(MAX) of the vector of row maxima.
+`quantize_model_weights` under a group issues ONE collective for all per-tensor weights.
 """
 from collections import OrderedDict
 import copy
@@ -31,18 +35,47 @@ _FLT_MIN = {"e5m2": 1.5258789E-05, "e4m3": 1.9531250E-03, "e3m4": 1.5625000E-02,
 
 _amax_group = None
 _amax_elem_base = None
+_amax_layout = None
+_amax_logical = None
+_amax_row_base = None
 _NO_SCALE_FMTS = (_hip.FMT_BF16, _hip.FMT_FP16, _hip.FMT_FP16_DAZ)  # their reference kernels take no scale
 
 
-def set_amax_process_group(group, elem_base=None):
+def set_amax_process_group(group, elem_base=None, layout=None, logical=None, row_base=None):
     """group: a torch.distributed process group (or None to go back to single-device scaling).
 
-    elem_base: where this rank's shard starts in the logical tensor, for the stochastic noise index --
-    None: equal-sized contiguous shards, `rank * tensor.numel()`; an int; or a callable
-    `elem_base(tensor) -> int` for ragged layouts (mpemu.sharded.shard_bounds gives the starts)."""
-    global _amax_group, _amax_elem_base
+    elem_base: where this rank's shard starts in the logical tensor, for the stochastic noise index (and, with
+    layout "flat", for the row it starts in) -- None: equal-sized contiguous shards, `rank * tensor.numel()`; an int;
+    or a callable `elem_base(tensor) -> int` for ragged layouts (mpemu.sharded.shard_bounds gives the starts).
+
+    layout: how per-channel / fine-grained tensors lie across the ranks (per-tensor scaling does not need it) --
+      None       : such calls raise under a group (a silent local row maximum would be wrong for straddling rows);
+      "channels" : dim 0 is sharded, every rank holds whole rows: no exchange.  row_base: this rank's first row in the
+                   logical tensor and the logical row count, for the stochastic call offsets (row r draws as call
+                   offset + r) -- None: equal shards, (rank * rows, world * rows); or a callable
+                   `row_base(tensor) -> (first_row, total_rows)`;
+      "flat"     : the tensor is this rank's contiguous piece of the flattened logical [rows, cols] tensor (an
+                   FSDP-style flat shard); `logical` = (rows, cols), or a callable `logical(tensor) -> (rows, cols)`.
+                   Per-row-segment maxima -> ONE all-reduce(MAX) of `rows` words -> cast with the global row scales.
+    """
+    global _amax_group, _amax_elem_base, _amax_layout, _amax_logical, _amax_row_base
+    if layout not in (None, "channels", "flat"):
+        raise ValueError("set_amax_process_group: layout must be None, 'channels' or 'flat', got %r" % (layout,))
+    if layout == "flat" and logical is None:
+        raise ValueError("set_amax_process_group: layout 'flat' needs logical=(rows, cols) or a callable")
+    if group is None and _amax_group is not None:
+        from .sharded import check_offsets
+        check_offsets()   # leaving the group: the one place a sync is free
     _amax_group = group
     _amax_elem_base = elem_base
+    _amax_layout = layout if group is not None else None
+    _amax_logical = logical if group is not None else None
+    _amax_row_base = row_base if group is not None else None
+
+
+def _device_tensor(tensor):
+    """True for tensors the HIP kernels can take (the CPU rehearsals of the group paths stand in for this)."""
+    return tensor.is_cuda
 
 
 def _shard_elem_base(tensor):
@@ -51,6 +84,36 @@ def _shard_elem_base(tensor):
     if _amax_elem_base is not None:
         return int(_amax_elem_base)
     return torch.distributed.get_rank(_amax_group) * tensor.numel()
+
+
+def _group_rows(src, dst, fmt, rmode, mode, flt_max, rows, clamp, fine_cols):
+    """Per-channel / fine-grained "max" quantisation of a tensor that is one rank's part of a logical tensor.
+    rows: dim 0 of the local tensor (per-channel) or local out-channels x groups (fine-grained, fine_cols = the
+    group size)."""
+    if _amax_layout is None:
+        raise RuntimeError("quantize_tensor: per-channel / fine-grained scaling under an amax process group needs "
+                           "set_amax_process_group(group, layout='channels' | 'flat'): a row that straddles ranks "
+                           "must take its maximum over all of them")
+    if _amax_layout == "channels":
+        offset = None
+        if rmode == _hip.STOCHASTIC:
+            if callable(_amax_row_base):
+                first, total = _amax_row_base(src)
+            else:
+                world = torch.distributed.get_world_size(_amax_group)
+                first, total = torch.distributed.get_rank(_amax_group) * rows, world * rows
+            offset = _hip.take_offsets(int(total)) + int(first)
+        _hip_quantize_rows(src, dst, fmt, rmode, flt_max, rows, clamp, offset=offset)
+        return
+    from .sharded import ShardedCaster
+    lrows, lcols = _amax_logical(src) if callable(_amax_logical) else _amax_logical
+    lrows, lcols = int(lrows), int(lcols)
+    if fine_cols:   # fine-grained: every (out-channel, group) pair of the logical tensor is a row of fine_cols
+        if lcols % fine_cols:
+            raise NotImplementedError("fine-grained scaling of a flat shard needs equal-sized groups")
+        lrows, lcols = lrows * (lcols // fine_cols), fine_cols
+    ShardedCaster(_amax_group, backend=_hip).quantize_rows_flat(src, lrows, lcols, _shard_elem_base(src), mode, flt_max,
+                                                                clamp=clamp, out=dst)
 
 
 class TensorQuantConfig(object):
@@ -218,11 +281,13 @@ class _ScaledCast(torch.autograd.Function):
     scaling over dim 0 (one scale per row of the flattened [rows, cols] view)."""
 
     @staticmethod
-    def forward(ctx, tensor, mode, inplace, flt_max, rows, clamp):
+    def forward(ctx, tensor, mode, inplace, flt_max, rows, clamp, fine_cols=0):
         fmt, rmode = _hip.parse_mode(mode)
         src = tensor.contiguous()
         dst = src if inplace else torch.empty_like(src)
-        if rows:
+        if rows and _amax_group is not None and fmt not in _NO_SCALE_FMTS:
+            _group_rows(src, dst, fmt, rmode, mode, flt_max, rows, clamp, fine_cols)
+        elif rows:
             _hip_quantize_rows(src, dst, fmt, rmode, flt_max, rows, clamp)
         elif _amax_group is not None:
             from .sharded import all_reduce_max_words
@@ -244,10 +309,10 @@ class _ScaledCast(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        return grad, None, None, None, None, None
+        return grad, None, None, None, None, None, None
 
 
-def _hip_quantize_rows(src, dst, fmt, rmode, flt_max, rows, clamp):
+def _hip_quantize_rows(src, dst, fmt, rmode, flt_max, rows, clamp, offset=None):
     """Per-row amax/scale/cast of a contiguous [rows, cols] buffer, no host sync.
 
     One launch of the rows kernel (one workgroup per row).  A few very long rows would leave most
@@ -257,14 +322,15 @@ def _hip_quantize_rows(src, dst, fmt, rmode, flt_max, rows, clamp):
         return
     cols = src.numel() // rows
     if rows >= 64 or cols <= (1 << 16):
-        _hip.quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=clamp)
+        _hip.quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=clamp, offset=offset)
         return
     s2, d2 = src.view(rows, -1), dst.view(rows, -1)
     ws = torch.zeros(rows, dtype=torch.int32, device=src.device)
     for r in range(rows):
         _hip.amax_(s2[r], ws[r:r + 1])
     for r in range(rows):
-        _hip.cast_scaled_(s2[r], d2[r], fmt, rmode, ws[r:r + 1], flt_max, clamp=clamp)
+        _hip.cast_scaled_(s2[r], d2[r], fmt, rmode, ws[r:r + 1], flt_max, clamp=clamp,
+                          offset=None if offset is None else offset + r)
 
 
 def _device_mean_scales(stat, flt_min, threshold):
@@ -290,7 +356,9 @@ class _GivenScaleCast(torch.autograd.Function):
         src = tensor.contiguous()
         dst = src if inplace else torch.empty_like(src)
         if fmt in _NO_SCALE_FMTS:
-            _hip.cast_(src, dst, fmt, rmode)  # these formats take no scale (cpp/fpemu_impl.cpp:1933-1957)
+            # these formats take no scale (cpp/fpemu_impl.cpp:1933-1957).  (Not reachable through quantize_tensor:
+            # they have no flt_min, so the "mean" scale rule raises first -- as in the reference, qutils.py:116-129.)
+            _hip.cast_(src, dst, fmt, rmode)
         elif not rows:
             _hip.cast_device_scale_(src, dst, fmt, rmode, scales)
         elif rows >= 64 or src.numel() // rows <= (1 << 16):
@@ -351,7 +419,7 @@ def _plan(qtconfig):
 def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
     """Single entry point for quantising a tensor (qutils.py:264-345)."""
     plan = getattr(qtconfig, "_plan", None) or _plan(qtconfig)
-    if plan[0] and tensor.is_cuda and _amax_group is None and not tensor.is_sparse:
+    if plan[0] and _amax_group is None and tensor.is_cuda and not tensor.is_sparse:
         ext = _hip.ext()
         if ext is not None and not _hip.tracing():
             # the two cases every hook call is: one native call does checks, allocation, launch(es) and the
@@ -366,7 +434,7 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
     mode = qtconfig.dtype.upper()
     if qtconfig.scheme is not None:
         mode += "_" + qtconfig.scheme.upper()
-    on_device = tensor.is_cuda and "INT" not in mode
+    on_device = _device_tensor(tensor) and "INT" not in mode
 
     if qtconfig.scaling is True:
         if qtconfig.scaling_method == "max" and on_device:
@@ -404,6 +472,9 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
         if (qtconfig.scaling_method == "mean" and on_device and tensor.dim() >= 1 and tensor.shape[0] > 0
                 and tensor.numel() > 0):
             # torch.mode of every row in one call, the scale rule elementwise, one cast launch for all rows
+            if _amax_group is not None and _amax_layout != "channels":
+                raise NotImplementedError("per-channel-mean scaling of a sharded tensor: the row statistic is not "
+                                          "reduced over the amax process group (layout 'channels' needs no exchange)")
             rows = tensor.shape[0]
             flat = tensor.detach().contiguous().view(rows, -1)
             scales = _device_mean_scales(torch.mode(flat, dim=1).values, qtconfig.get_flt_min(), 1e-6)
@@ -424,6 +495,13 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
         return tensor if inplace else tensor_q
 
     if qtconfig.fine_grained is True:
+        if _amax_group is not None and _amax_layout == "flat" and qtconfig.scaling_method == "max" and on_device:
+            # a flat shard carries no shape: the groups come from the logical [out, in] tensor
+            lcols = int((_amax_logical(tensor) if callable(_amax_logical) else _amax_logical)[1])
+            chunks = max(1, int(lcols / qtconfig.group_size))
+            size = -(-lcols // chunks)
+            q = _ScaledCast.apply(tensor.detach(), mode, inplace, qtconfig.get_flt_max(), 1, False, size)
+            return tensor if inplace else q
         if (qtconfig.scaling_method == "max" and on_device and tensor.dim() >= 2 and tensor.is_contiguous()
                 and tensor.numel() > 0):
             # groups are torch.chunk pieces of dim 1; when they are equal-sized every (out-channel,
@@ -433,8 +511,10 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
             size = -(-in_ch // chunks)
             if in_ch % size == 0:
                 rows = tensor.shape[0] * (in_ch // size)
-                q = _ScaledCast.apply(tensor.detach(), mode, inplace, qtconfig.get_flt_max(), rows, False)
+                q = _ScaledCast.apply(tensor.detach(), mode, inplace, qtconfig.get_flt_max(), rows, False, size)
                 return tensor if inplace else q
+            if _amax_group is not None:
+                raise NotImplementedError("fine-grained scaling with ragged groups under an amax process group")
         tensor_q = None if inplace else torch.zeros_like(tensor)
         for k in range(tensor.shape[0]):
             crs = tensor.select(0, k).detach()
@@ -501,8 +581,13 @@ def quantize_model_weights(model, model_qconfig_dict):
     device) and quantised in place by fpemu_quantize_per_tensor_multi: two launches per 32 weights instead of one to
     three per weight, bit for bit the loop's result (tensor i of a call is quantised exactly as the single-tensor
     call would; deterministic modes consume no call offsets, so the order of the calls does not matter).
+    Under an amax process group (every weight a shard of a logical weight) the collection goes amax words ->
+    ONE all-reduce(MAX) of all the words -> multi-tensor cast, instead of one collective per weight.
+    A storage that several modules share (tied weights) enters the batch once; its later occurrences are quantised
+    after the batch, one by one, so the tensor ends as q(q(w)) exactly as in the reference's sequential loop.
     Everything else takes the loop."""
     batches = OrderedDict()
+    seen, again = set(), []
     for name, module in model.named_modules():
         cfg = model_qconfig_dict.get(name)
         if cfg is None or cfg.wt_qconfig is None:
@@ -510,16 +595,26 @@ def quantize_model_weights(model, model_qconfig_dict):
         qt = cfg.wt_qconfig
         w = module.weight.data
         plan = getattr(qt, "_plan", None) or _plan(qt)
-        if (plan[0] == 1 and plan[3] != _hip.STOCHASTIC and w.is_cuda and w.is_contiguous() and not w.is_sparse
-                and _amax_group is None and w.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+        if (plan[0] == 1 and plan[3] != _hip.STOCHASTIC and _device_tensor(w) and w.is_contiguous() and not w.is_sparse
+                and w.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+            key = (w.data_ptr(), w.numel())
+            if key in seen:
+                again.append((module, qt, name))
+                continue
+            seen.add(key)
             batches.setdefault((plan[2], plan[3], plan[4], w.dtype, w.device), []).append(w)
         else:
             quantize_weights_of_a_module(module, qt, name=name)
     for (fmt, rmode, flt_max, _, _), weights in batches.items():
-        if len(weights) == 1:
+        if _amax_group is not None:
+            from .sharded import ShardedCaster
+            ShardedCaster(_amax_group, backend=_hip).quantize_per_tensor_multi(weights, (fmt, rmode), flt_max)
+        elif len(weights) == 1:
             _hip.quantize_per_tensor_(weights[0], weights[0], fmt, rmode, flt_max)
         else:
             _hip.quantize_per_tensor_multi_(weights, fmt, rmode, flt_max)
+    for module, qt, name in again:
+        quantize_weights_of_a_module(module, qt, name=name)
 
 
 def _active(qtconfig):

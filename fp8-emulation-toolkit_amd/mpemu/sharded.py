@@ -37,17 +37,86 @@ def group_backend(group=None):
     return str(dist.get_backend(group)).lower()
 
 
+class _OffsetGuard(object):
+    """The stochastic call offset must advance in lock-step on every rank (it selects the Philox stream of a call).
+    On the nccl path the (o, -o) pair rides along with the amax words through the all-reduce(MAX) and is compared ON
+    THE DEVICE into an error word -- no host sync on the hot path.  The word reaches the host through an asynchronous
+    copy into pinned memory that later calls poll (event query, never a wait): a disagreement raises a few calls
+    after it happened.  check() is the synchronous form (teardown, tests, MPEMU_CHECK_OFFSETS=1)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.on_gpu = self.device.type == "cuda"
+        self.host = torch.zeros(1, dtype=torch.int32, pin_memory=True) if self.on_gpu else self.err
+        self.event = None
+
+    def note(self, pair):
+        """pair: int32[2] on the guard's device holding (max over ranks of v, max over ranks of -v)."""
+        self.err.bitwise_or_((pair[0:1] + pair[1:2]).ne(0).to(torch.int32))
+
+    def _raise(self):
+        self.err.zero_()
+        self.host.zero_()
+        self.event = None
+        raise RuntimeError("mpemu.sharded: ranks disagree on the stochastic call offset: every rank must issue the "
+                           "same sequence of stochastic casts")
+
+    def poll(self):
+        """Non-blocking: look at the last asynchronous copy if it has landed, then start the next one."""
+        if not self.on_gpu:
+            if int(self.err[0]) != 0:
+                self._raise()
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self.event is not None:
+            if not self.event.query():
+                return
+            self.event = None
+            if int(self.host[0]) != 0:
+                self._raise()
+        self.host.copy_(self.err, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(self.device))
+
+    def check(self):
+        """Blocking: raise if any call so far saw disagreeing offsets."""
+        if int(self.err.cpu()[0]) != 0:
+            self._raise()
+
+
+_guards = {}
+
+
+def offset_guard(device):
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    g = _guards.get(dev)
+    if g is None:
+        g = _guards[dev] = _OffsetGuard(dev)
+    return g
+
+
+def check_offsets():
+    """Synchronous verification of every device's offset guard (call at teardown or wherever a sync is free)."""
+    for g in list(_guards.values()):
+        g.check()
+
+
 def all_reduce_max_words(words, group=None, check_equal=None):
     """In-place MAX all-reduce of an int32 device (or CPU) tensor of amax words over `group`.
 
     nccl: on the device, in stream order.  Other backends: staged through the host (module docstring).
     check_equal: optional Python int that every rank must hold the same value of (the stochastic call
-    offset): verified for free on the host-staged path, and on the nccl path when MPEMU_CHECK_OFFSETS=1
-    (it costs a host sync there).  Raises RuntimeError when ranks disagree."""
+    offset).  Host-staged path: verified on the spot, for free.  nccl path: the pair (v, -v) is reduced with the
+    words and compared on the device into an error word (_OffsetGuard) that later calls poll without blocking;
+    MPEMU_CHECK_OFFSETS=1 makes every call check synchronously.  Raises RuntimeError when ranks disagree."""
     backend = group_backend(group)
     if backend is None or dist.get_world_size(group) == 1:
         return words
-    verify = check_equal is not None and (backend != "nccl" or _CHECK_OFFSETS)
+    verify = check_equal is not None
     if verify:
         # max(v) and max(-v) agree in magnitude on every rank iff all ranks hold the same v
         v = int(check_equal) & 0x3FFFFFFF
@@ -57,12 +126,19 @@ def all_reduce_max_words(words, group=None, check_equal=None):
         buf = words
     if backend == "nccl":
         dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
-        host = buf[-2:].cpu() if verify else None
-    else:
-        host = buf.cpu() if buf.is_cuda else buf
-        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
-        if buf.is_cuda:
-            buf.copy_(host)
+        if verify:
+            words.reshape(-1).copy_(buf[:-2])
+            guard = offset_guard(words.device)
+            guard.note(buf[-2:])
+            if _CHECK_OFFSETS:
+                guard.check()
+            else:
+                guard.poll()
+        return words
+    host = buf.cpu() if buf.is_cuda else buf
+    dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+    if buf.is_cuda:
+        buf.copy_(host)
     if verify:
         if int(host[-2]) != -int(host[-1]):
             raise RuntimeError("mpemu.sharded: ranks disagree on the stochastic call offset (max %d, min %d): "
@@ -72,17 +148,34 @@ def all_reduce_max_words(words, group=None, check_equal=None):
     return words
 
 
-import os as _os
-
-_CHECK_OFFSETS = _os.environ.get("MPEMU_CHECK_OFFSETS", "0") not in ("", "0")
-
-
 def shard_bounds(numel, world_size, rank, align=SHARD_ALIGN):
     """[start, end) of `rank`'s contiguous shard of a flat tensor of `numel` elements."""
     per = -(-numel // world_size)
     per = -(-per // align) * align
     start = min(numel, rank * per)
     return start, min(numel, start + per)
+
+
+def row_segments(numel, cols, start):
+    """The row segments of a contiguous piece [start, start + numel) of a flattened [rows, cols] tensor:
+    a list of (local_offset, nrows, ncols, row0, col0) -- at most a partial head row, a run of whole rows and a
+    partial tail row (a piece inside one row is a single segment)."""
+    segs = []
+    pos, end = start, start + numel
+    if pos < end and pos % cols:                       # head: the rest of row pos // cols
+        stop = min(end, (pos // cols + 1) * cols)
+        segs.append((pos - start, 1, stop - pos, pos // cols, pos % cols))
+        pos = stop
+    whole = (end - pos) // cols
+    if whole > 0:
+        segs.append((pos - start, whole, cols, pos // cols, 0))
+        pos += whole * cols
+    if pos < end:                                      # tail: the beginning of the next row
+        segs.append((pos - start, 1, end - pos, pos // cols, 0))
+    return segs
+
+
+_LONG_ROW = 1 << 16   # rows longer than this, fewer than 64 of them: full-width launches row by row (as qutils does)
 
 
 class ShardedCaster(object):
@@ -117,6 +210,71 @@ class ShardedCaster(object):
         if self._world() > 1:
             all_reduce_max_words(words, self.group)
         return words
+
+    def quantize_per_tensor_multi(self, shards, mode, flt_max, inplace=True, clamp=True, words=None):
+        """Per-tensor "max" quantisation of a LIST of shards (each this rank's piece of its own logical tensor) with
+        ONE collective for the whole list: per-tensor amax words in a few launches -> one all-reduce(MAX) of
+        len(shards) words -> multi-tensor cast with device-side scales.  Replaces a loop of quantize_per_tensor
+        (one collective per tensor; the reference's loop is qutils.py:470-475).  Deterministic modes (the
+        multi-tensor cast indexes noise from element 0 of each buffer).  Returns (outputs, words)."""
+        shards = list(shards)
+        fmt, rmode = mode if isinstance(mode, tuple) else self.ops.parse_mode(mode)
+        if rmode == self.ops.STOCHASTIC and self._world() > 1:
+            raise NotImplementedError("mpemu.sharded: quantize_per_tensor_multi of sharded tensors is for "
+                                      "deterministic rounding modes; use quantize_per_tensor per tensor")
+        if not shards:
+            return [], words
+        if words is None:
+            words = torch.empty(len(shards), dtype=torch.int32, device=shards[0].device)
+        self.ops.amax_multi_(shards, words)
+        if self._world() > 1:
+            all_reduce_max_words(words, self.group)
+        outs = shards if inplace else [torch.empty_like(t) for t in shards]
+        self.ops.cast_multi_scaled_(shards, fmt, rmode, words, flt_max, dsts=outs, clamp=clamp)
+        return outs, words
+
+    def quantize_rows_flat(self, shard, rows, cols, start, mode, flt_max, clamp=True, inplace=False, seed=None,
+                           offset=None, out=None):
+        """quantize_tensor's per-channel "max" policy (reference qutils.py:289-311; clamp=False: the fine-grained
+        one, :313-337) for this rank's contiguous piece [start, start + shard.numel()) of a flattened [rows, cols]
+        tensor whose rows may straddle ranks: per-row-segment maxima into a vector of `rows` words -> ONE
+        all-reduce(MAX) of that vector -> every segment cast with its row's scale.  Stochastic modes: row r draws as
+        call `offset + r` and column c as element c of that call, whatever the cut, so the result is the
+        single-device result bit for bit; the call consumes `rows` offsets on every rank.
+        out: optional contiguous result buffer (may be `shard` itself); returns (result, row amax words)."""
+        fmt, rmode = self.ops.parse_mode(mode)
+        n = shard.numel()
+        if start < 0 or start + n > rows * cols:
+            raise ValueError("mpemu.sharded: piece [%d, %d) lies outside the %d x %d tensor" % (start, start + n, rows, cols))
+        if not shard.is_contiguous():
+            raise ValueError("mpemu.sharded: the piece must be contiguous")
+        flat = shard.view(-1)
+        result = shard if (inplace or out is shard) else (out if out is not None else torch.empty_like(shard))
+        out = result.view(-1)
+        if offset is None:
+            offset = self.ops.take_offsets(rows) if rmode == self.ops.STOCHASTIC else 0
+        words = torch.zeros(rows, dtype=torch.int32, device=shard.device)   # rows this rank holds nothing of stay 0
+        segs = row_segments(n, cols, start)
+        for lo, nr, nc, r0, c0 in segs:
+            piece = flat[lo:lo + nr * nc]
+            if nr < 64 and nc > _LONG_ROW:
+                for r in range(nr):
+                    self.ops.amax_(piece[r * nc:(r + 1) * nc], words[r0 + r:r0 + r + 1])
+            else:
+                self.ops.amax_rows_(piece, nr, words[r0:r0 + nr])
+        if self._world() > 1:
+            all_reduce_max_words(words, self.group, check_equal=offset if rmode == self.ops.STOCHASTIC else None)
+        for lo, nr, nc, r0, c0 in segs:
+            src, dst = flat[lo:lo + nr * nc], out[lo:lo + nr * nc]
+            if nr < 64 and nc > _LONG_ROW:
+                for r in range(nr):
+                    self.ops.cast_scaled_(src[r * nc:(r + 1) * nc], dst[r * nc:(r + 1) * nc], fmt, rmode,
+                                          words[r0 + r:r0 + r + 1], flt_max, clamp=clamp, seed=seed,
+                                          offset=offset + r0 + r, elem_base=c0)
+            else:
+                self.ops.cast_rows_amax_(src, dst, nr, fmt, rmode, words[r0:r0 + nr], flt_max, clamp=clamp, seed=seed,
+                                         offset=offset + r0, col_base=c0)
+        return result, words
 
     def quantize_per_tensor(self, shard, mode, flt_max, elem_base=0, inplace=False, clamp=True,
                             seed=None, offset=None, amax_word=None):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FPEMU_ABI_VERSION 8
+#define FPEMU_ABI_VERSION 9
 
 /* Storage dtype of in/out buffers. */
 enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
@@ -69,7 +69,7 @@ enum {
 /* Error codes (negative). */
 enum {
   FPEMU_OK = 0,
-  FPEMU_EINVAL = -1,       /* null pointer, bad dtype/fmt/rmode id, non-finite scale (+-Inf, NaN) */
+  FPEMU_EINVAL = -1,       /* null pointer, bad dtype/fmt/rmode id, scale > FLT_MAX (the reference's test, cpp:772-776) */
   FPEMU_EMODE = -2,        /* mode string not recognised (the reference silently no-ops) */
   FPEMU_EUNSUPPORTED = -3, /* recognised but not built (no such case at present) */
   FPEMU_EALIGN = -4        /* pointer not aligned to the element size */
@@ -122,6 +122,20 @@ int fpemu_cast_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, i
 int fpemu_quantize_per_tensor_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, int fmt, int rmode,
                                     float flt_max, int clamp, uint32_t *ws, uint64_t ws_words, uint64_t seed,
                                     uint64_t offset, void *stream);
+
+/* The two halves of fpemu_quantize_per_tensor_multi for tensors that are SHARDS of larger tensors (one process per
+ * GPU): between them the caller all-reduces (MAX) the `count` words over its process group -- one collective for
+ * the whole list, instead of one per weight as a loop of quantize_weights_of_a_module would issue
+ * (reference qutils.py:470-475; the reference itself has no collective).
+ *   fpemu_amax_multi        : amax_words[i] = bit pattern of max |tensor i| (the words are zeroed first, in stream
+ *                             order; empty tensors stay 0), two launches + one per 32 tensors;
+ *   fpemu_cast_multi_scaled : tensor i is cast exactly as fpemu_cast_scaled(in_i, out_i, n_i, ..., amax_words + i,
+ *                             flt_max, clamp, seed, offset + i, elem_base 0), one launch per 32 tensors.
+ * Without the exchange the pair equals fpemu_quantize_per_tensor_multi bit for bit. */
+int fpemu_amax_multi(const fpemu_tensor_t *tensors, uint64_t count, int dtype, uint32_t *amax_words, void *stream);
+int fpemu_cast_multi_scaled(const fpemu_tensor_t *tensors, uint64_t count, int dtype, int fmt, int rmode,
+                            const uint32_t *amax_words, float flt_max, int clamp, uint64_t seed, uint64_t offset,
+                            void *stream);
 
 /* Mirror of the pybind `forward` signature (hip/fpemu_impl.cpp:27-37): mode string, size,
  * scale, block_norm, block_size.  inplace <=> out == in.  block_norm: as the reference
@@ -212,6 +226,23 @@ int fpemu_quantize_rows(const void *in, void *out, uint64_t rows, uint64_t cols,
  * fpemu_cast_device_scale).  Formats without a scale (BF16 / FP16) are rejected. */
 int fpemu_cast_rows_scaled(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt, int rmode,
                            const float *scales, uint64_t seed, uint64_t offset, void *stream);
+
+/* The two halves of fpemu_quantize_rows for a [rows, cols] tensor whose rows are spread over several GPUs (SURVEY
+ * 8(e): "all-reduce(max) of the C-vector of amaxes"; the reference's per-channel loop, qutils.py:289-311, knows one
+ * device only).  The buffer handed in is `rows` row SEGMENTS of `cols` elements each, contiguous:
+ *   fpemu_amax_rows      : amax_bits[r] = bit pattern of max |segment r| (plain store; a NaN wins, as torch.max);
+ *   -- the caller combines the vectors of all ranks with an integer MAX all-reduce --
+ *   fpemu_cast_rows_amax : segment r is cast with scale_from_amax(amax_bits[r], flt_max, clamp) (clamp != 0: the
+ *                          per-channel rule qutils.py:308; 0: the fine-grained one, :328-330).  Stochastic modes:
+ *                          segment r draws as call `offset + r` and its element c as element `col_base + c` of that
+ *                          call, i.e. exactly what fpemu_quantize_rows draws for column col_base + c of row r of the
+ *                          whole tensor -- results do not depend on how the rows are cut.
+ * Without the exchange (col_base 0) the pair equals fpemu_quantize_rows bit for bit.  Formats without a scale
+ * (BF16 / FP16) are rejected by the cast. */
+int fpemu_amax_rows(const void *in, uint64_t rows, uint64_t cols, int dtype, uint32_t *amax_bits, void *stream);
+int fpemu_cast_rows_amax(const void *in, void *out, uint64_t rows, uint64_t cols, int dtype, int fmt, int rmode,
+                         const uint32_t *amax_bits, float flt_max, int clamp, uint64_t seed, uint64_t offset,
+                         uint64_t col_base, void *stream);
 
 /* Block-normalised cast: the reference's forward(..., block_norm = true, block_size) for the formats
  * whose kernels have that branch (E5M2_Kernel cpp/fpemu_impl.cpp:778-815, E4M3_Kernel :1149-1190,

@@ -34,7 +34,7 @@ def amax_(src, amax_bits):
 
 
 def cast_scaled_(src, dst, fmt, rmode, amax_bits, flt_max, clamp=True, seed=None, offset=None, elem_base=0):
-    vmax = np.array([int(amax_bits[0])], dtype=np.uint32).view(np.float32)[0]
+    vmax = np.array([int(amax_bits[0])], dtype=np.int64).astype(np.uint32).view(np.float32)[0]
     s = orc.scale_from_amax(vmax, flt_max, clamp=clamp)
     return cast_(src, dst, fmt, rmode, scale=s, seed=seed, offset=offset, elem_base=elem_base)
 
@@ -60,3 +60,73 @@ def set_rng_state(state):
 
 def stream_workspace(t):
     return _ws
+
+
+def take_offsets(count):
+    global _offset
+    o = _offset
+    _offset += int(count)
+    return o
+
+
+def get_rng_state():
+    return 0, _offset
+
+
+FMT_BF16, FMT_FP16, FMT_FP16_DAZ = orc.FMT["BF16"], orc.FMT["FP16"], orc.FMT["FP16_DAZ"]
+
+
+def _word(a):
+    return int(np.array([orc.amax(a)], dtype=np.float32).view(np.uint32)[0])
+
+
+def _vmax(word):
+    return np.array([int(word)], dtype=np.int64).astype(np.uint32).view(np.float32)[0]
+
+
+def amax_rows_(src, rows, words):
+    a = src.numpy().reshape(rows, -1)
+    for r in range(rows):
+        words[r] = np.int32(np.uint32(_word(a[r])).view(np.int32)) if a.shape[1] else 0
+    return words
+
+
+def cast_rows_amax_(src, dst, rows, fmt, rmode, words, flt_max, clamp=True, seed=None, offset=None, col_base=0):
+    a = src.numpy().reshape(rows, -1)
+    d = dst.view(rows, -1)
+    if offset is None:
+        offset = take_offsets(rows) if rmode == STOCHASTIC else 0
+    for r in range(rows):
+        s = orc.scale_from_amax(_vmax(words[r]), flt_max, clamp=clamp)
+        y = orc.cast(a[r], _mode(fmt, rmode), scale=s, seed=seed or 0, offset=offset + r, elem_base=col_base)
+        d[r].copy_(torch.from_numpy(y))
+    return dst
+
+
+def quantize_rows_(src, dst, rows, fmt, rmode, flt_max, clamp=True, offset=None):
+    words = torch.zeros(rows, dtype=torch.int32)
+    amax_rows_(src, rows, words)
+    return cast_rows_amax_(src, dst, rows, fmt, rmode, words, flt_max, clamp=clamp, offset=offset)
+
+
+def amax_multi_(srcs, words):
+    for i, t in enumerate(srcs):
+        words[i] = np.int32(np.uint32(_word(t.numpy())).view(np.int32)) if t.numel() else 0
+    return words
+
+
+def cast_multi_scaled_(srcs, fmt, rmode, words, flt_max, dsts=None, clamp=True, seed=None, offset=None):
+    dsts = srcs if dsts is None else dsts
+    if offset is None:
+        offset = take_offsets(len(srcs)) if rmode == STOCHASTIC else 0
+    for i, (a, b) in enumerate(zip(srcs, dsts)):
+        cast_scaled_(a, b, fmt, rmode, words[i:i + 1], flt_max, clamp=clamp, seed=seed, offset=offset + i)
+    return dsts
+
+
+def ext():
+    return None
+
+
+def tracing():
+    return False

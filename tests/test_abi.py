@@ -64,10 +64,12 @@ def test_argument_errors_without_gpu():
     assert L.fpemu_gemm_f32(18, 16, 16, 4, 4, 4, 4, 4, 4, 1.0, 0, 0, 1, None) == -4   # misaligned C
     assert L.fpemu_cast(18, 18, 16, 0, 1, 1, 1.0, 0, 0, 0, None) == -4           # misaligned fp32
     assert L.fpemu_cast(16, 16, 16, 0, 1, 1, float("inf"), 0, 0, 0, None) == -1  # cpp:772-776
-    assert L.fpemu_cast(16, 16, 16, 0, 1, 1, float("-inf"), 0, 0, 0, None) == -1
-    assert L.fpemu_cast(16, 16, 16, 0, 1, 1, float("nan"), 0, 0, 0, None) == -1  # any non-finite scale
     assert b"scale" in L.fpemu_last_error()
-    assert L.fpemu_forward(16, 16, 0, b"E4M3_RNE", 16, float("nan"), 0, 1, 0, 0, None) == -1
+    # `scale > FLT_MAX` is the reference's whole check: NaN / -Inf scales are not rejected (they give what the
+    # arithmetic gives; tests/test_gpu_qutils.py runs one).  n = 0 here: nothing is launched without a GPU.
+    assert L.fpemu_cast(16, 16, 0, 0, 1, 1, float("-inf"), 0, 0, 0, None) == 0
+    assert L.fpemu_cast(16, 16, 0, 0, 1, 1, float("nan"), 0, 0, 0, None) == 0
+    assert L.fpemu_forward(16, 16, 0, b"E4M3_RNE", 16, float("inf"), 0, 1, 0, 0, None) == -1
     assert L.fpemu_quantize_per_tensor_static(16, 16, (1 << 36) + 1, 0, 1, 1, 448.0, 1, None, 0, 0, None) == -1
     assert L.fpemu_quantize_per_tensor_static(16, 16, 0, 0, 1, 1, 448.0, 1, None, 0, 0, None) == 0   # empty
     assert L.fpemu_cast(16, 16, 0, 0, 1, 1, 1.0, 0, 0, 0, None) == 0             # empty: no launch
@@ -84,7 +86,20 @@ def test_argument_errors_without_gpu():
     assert L.fpemu_cast_multi(tp, 2, 0, 1, 1, 1.0, 0, 0, None) == -1             # null buffer with n > 0
     assert L.fpemu_cast_multi(None, 2, 0, 1, 1, 1.0, 0, 0, None) == -1
     assert L.fpemu_cast_multi(tp, 1, 0, 1, 5, 1.0, 0, 0, None) == -1             # undefined mode pair
-    assert L.fpemu_cast_multi(tp, 1, 0, 1, 1, float("nan"), 0, 0, None) == -1
+    assert L.fpemu_cast_multi(tp, 1, 0, 1, 1, float("inf"), 0, 0, None) == -1   # scale > FLT_MAX
+    assert L.fpemu_cast_multi(tp, 1, 0, 1, 1, float("nan"), 0, 0, None) == 0    # not rejected (one empty tensor)
+    # the group-aware halves (ABI 9)
+    assert L.fpemu_amax_multi(tp, 0, 0, None, None) == 0
+    assert L.fpemu_amax_multi(tp, 1, 0, None, None) == -1                        # null words
+    assert L.fpemu_amax_multi(tp, 2, 0, 16, None) == -1                          # null buffer with n > 0
+    assert L.fpemu_cast_multi_scaled(tp, 1, 0, 3, 1, 16, 1.0, 1, 0, 0, None) == -1   # BF16 takes no scale
+    assert L.fpemu_cast_multi_scaled(tp, 2, 0, 1, 1, 16, 448.0, 1, 0, 0, None) == -1 # null buffer with n > 0
+    assert L.fpemu_amax_rows(16, 0, 8, 0, None, None) == 0                       # no rows
+    assert L.fpemu_amax_rows(16, 4, 8, 0, None, None) == -1                      # null words
+    assert L.fpemu_amax_rows(None, 4, 8, 0, 16, None) == -1
+    assert L.fpemu_amax_rows(18, 4, 8, 0, 16, None) == -4
+    assert L.fpemu_cast_rows_amax(16, 16, 4, 8, 0, 1, 1, None, 448.0, 1, 0, 0, 0, None) == -1
+    assert L.fpemu_cast_rows_amax(16, 16, 4, 0, 0, 1, 1, 16, 448.0, 1, 0, 0, 0, None) == 0    # empty rows
     tab[1].inp, tab[1].out = 18, 18
     assert L.fpemu_cast_multi(tp, 2, 0, 1, 1, 1.0, 0, 0, None) == -4             # misaligned fp32
     assert L.fpemu_amax(16, 0, 0, 16, None) == 0

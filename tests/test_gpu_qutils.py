@@ -197,6 +197,17 @@ def test_mean_policies_device_side_equal_the_host_loop(scaling, scheme, dt):
             assert (got.data_ptr() == xin.data_ptr()) == inplace
 
 
+def test_mean_policies_are_undefined_for_formats_without_flt_min():
+    """bfloat16 / float16 have no flt_min (reference qutils.py:116-129 returns None), so the "mean" scale rule
+    `flt_min / mean` raises TypeError there and here alike: _GivenScaleCast's no-scale branch cannot be reached
+    through quantize_tensor (ADVICE r02 asked what offsets it consumes under a stochastic scheme)."""
+    from mpemu import qutils
+    x = torch.randn(8, 32, device=DEV)
+    for scaling in ("per-channel-mean", "per-tensor-mean"):
+        with pytest.raises(TypeError):
+            qutils.quantize_tensor(x, qutils.TensorQuantConfig("bfloat16", "stochastic", scaling), None)
+
+
 def test_mean_policy_per_tensor_is_differentiable_ste():
     from mpemu import qutils
     x = torch.randn(64, 32, device=DEV, requires_grad=True)
@@ -204,3 +215,24 @@ def test_mean_policy_per_tensor_is_differentiable_ste():
     y = qutils.quantize_tensor(x, cfg, None, inplace=False)
     y.sum().backward()
     assert torch.equal(x.grad, torch.ones_like(x))
+
+
+def test_nan_and_negative_infinite_scales_run_as_in_the_reference():
+    """`scale > FLT_MAX` is the reference's whole check (cpp/fpemu_impl.cpp:772-776): a NaN scale -- flt_max / vmax of a
+    tensor holding a NaN on a host-scaled path -- is not an error, the arithmetic yields NaNs; +Inf is reported."""
+    from mpemu import qutils
+    x = torch.tensor([1.0, -2.5, 0.0, 300.0] * 64, device=DEV)
+    for mode in ("E4M3_RNE", "E5M2_RNE"):
+        got = qutils.fpemu_device_fn(x, mode, inplace=False, scale=float("nan"))
+        assert torch.isnan(got).all()
+        got = qutils.fpemu_device_fn(x, mode, inplace=False, scale=float("-inf"))
+        want = orc.cast(x.cpu().numpy(), mode, scale=float("-inf"))
+        assert_bits_equal(got.cpu().numpy(), want, mode + " scale -inf", nan_payload_ok=True)
+    with pytest.raises(ValueError):
+        qutils.fpemu_device_fn(x, "E4M3_RNE", inplace=False, scale=float("inf"))
+    # the host-scaled branch of quantize_tensor with a NaN in the tensor: fine-grained groups on a non-contiguous view
+    w = torch.randn(6, 16, device=DEV).t()          # [16, 6], not contiguous
+    w[3, 2] = float("nan")
+    cfg = qutils.TensorQuantConfig("e4m3", "rne", "fine-grained", group_size=2)
+    q = qutils.quantize_tensor(w, cfg, None, inplace=False)
+    assert torch.isnan(q[3]).any() and torch.isfinite(q[4]).all()
