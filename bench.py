@@ -76,6 +76,20 @@ def time_launches(fn, steps):
     return sum(per) / len(per), min(per)
 
 
+def time_batch(fn, launches=20, warm=3):
+    """Average device time of one launch from TWO HIP events around `launches` back-to-back launches (an event per
+    launch puts a marker packet, 5-10 us on this runtime, inside every interval: visible for 50-100 us kernels)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / launches
+
+
 def checksum64(t):
     """Two 64-bit sums over the bit patterns of a tensor (plain and position-weighted), wrapping."""
     b = t.reshape(-1).view(torch.int32 if t.element_size() == 4 else torch.int16)
@@ -152,6 +166,8 @@ def load_ceilings():
     L.ceil_read.argtypes = [vp, vp, u64, vp]
     L.ceil_write.argtypes = [vp, u64, vp]
     L.ceil_copy.argtypes = [vp, vp, u64, ctypes.c_int, vp]
+    L.ceil_mfma.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+    L.ceil_valu.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
     return L
 
 
@@ -333,17 +349,36 @@ def main():
                 all_reduce_max_words(ws)
             hip.cast_scaled_(xf, y, fmt, rm, ws, 448.0, clamp=True, seed=1, offset=0, elem_base=base)
 
-        for _ in range(3):
-            scaled_step()
-        s_avg, _ = time_launches(scaled_step, 10)
+        barrier()
+        s_avg = reduce_max_f64(time_batch(scaled_step, launches=20, warm=3))
         gmax = reduce_max_f64(float(xf.abs().max().item()))
         word_ok = int(ws.item()) == int(np.float32(gmax).view(np.uint32))
         sc = orc.scale_from_amax(np.float32(gmax), 448.0)
         verified["scaled_per_tensor"] = word_ok and same(y[:HEAD], orc.cast(hxf, args.mode, scale=sc, seed=1, offset=0,
                                                                             elem_base=base))
+        # the collective alone: all-reduce(MAX) of the one amax word, back to back (RCCL: two events on the stream
+        # the all-reduce is enqueued on; host-staged backends: wall clock around the synchronising calls)
+        collective_us = None
+        if world > 1:
+            cw = torch.zeros(1, dtype=torch.int32, device=dev)
+            for _ in range(5):
+                all_reduce_max_words(cw)
+            torch.cuda.synchronize()
+            barrier()
+            if backend == "nccl":
+                collective_us = time_batch(lambda: all_reduce_max_words(cw), launches=50, warm=0) * 1e3
+            else:
+                c0 = time.perf_counter()
+                for _ in range(50):
+                    all_reduce_max_words(cw)
+                collective_us = (time.perf_counter() - c0) / 50 * 1e6
+            collective_us = round(reduce_max_f64(collective_us), 2)
         extras["scaled_per_tensor"] = {"ms_per_step": round(s_avg, 5),
                                        "GB/s_per_gpu": round(12 * n / (s_avg * 1e-3) / 1e9, 1),
+                                       "elements/s_whole_job": round(world * n / (s_avg * 1e-3), 1),
                                        "collective": "all_reduce(max) of 4 B" if world > 1 else "none",
+                                       "collective_us": collective_us,
+                                       "timing": "two HIP events around 20 steps (amax + all-reduce + cast), max over ranks",
                                        "verified": verified["scaled_per_tensor"]}
 
         if world == 1:
@@ -351,9 +386,7 @@ def main():
             def fused_step():
                 hip.quantize_per_tensor_(xf, y, fmt, rm, 448.0)
 
-            for _ in range(3):
-                fused_step()
-            f_avg, _ = time_launches(fused_step, 10)
+            f_avg = time_batch(fused_step, launches=20, warm=3)
             verified["fused_per_tensor"] = same(y[:HEAD], orc.cast(hxf, args.mode, scale=sc))
             extras["fused_per_tensor"] = {"ms_per_step": round(f_avg, 5),
                                           "GB/s_per_gpu": round(12 * n / (f_avg * 1e-3) / 1e9, 1),
@@ -436,8 +469,7 @@ def main():
         def inplace_step():
             hip.cast_(y, y, fmt, rm, scale=1.0)
 
-        inplace_step()
-        i_avg, _ = time_launches(inplace_step, 10)
+        i_avg = time_batch(inplace_step, launches=10, warm=1)
         verified["inplace"] = same(y[:HEAD], orc.cast(orc.cast(hx, args.mode), args.mode))
         extras["inplace"] = {"ms": round(i_avg, 5), "GB/s": round(8 * n / (i_avg * 1e-3) / 1e9, 1),
                              "verified": verified["inplace"]}
@@ -450,8 +482,7 @@ def main():
                 def mstep(f=f, r=r):
                     hip.cast_(x, y, f, r, scale=1.0, seed=1, offset=3)
 
-                mstep()
-                a, _ = time_launches(mstep, 10)
+                a = time_batch(mstep, launches=10, warm=1)
                 modes[m] = round(8 * n / (a * 1e-3) / 1e9, 1)
                 modes_ok[m] = same(y[:HEAD], orc.cast(hx, m, seed=1, offset=3))
             extras["modes_GB/s"] = modes
@@ -475,8 +506,7 @@ def main():
                 def rows_step(xr=xr, yr=yr, rows=rows):
                     hip.quantize_rows_(xr, yr, rows, fmt, rm, 448.0)
 
-                rows_step()
-                r_avg, _ = time_launches(rows_step, 10)
+                r_avg = time_batch(rows_step, launches=20, warm=3)
                 hrows = max(1, HEAD // cols)
                 verified[name] = same(yr[: hrows * cols], rows_oracle(xf[: hrows * cols].cpu().numpy(), cols))
                 extras[name] = {"ms": round(r_avg, 5), "GB/s": round(8 * xr.numel() / (r_avg * 1e-3) / 1e9, 1),
@@ -490,8 +520,7 @@ def main():
             def bf16_step():
                 hip.cast_(xb, yb, fmt, rm, scale=1.0)
 
-            bf16_step()
-            b_avg, _ = time_launches(bf16_step, 10)
+            b_avg = time_batch(bf16_step, launches=20, warm=3)
             hb = xb[:HEAD].view(torch.int16).cpu().numpy().view(np.uint16)
             gb = yb[:HEAD].view(torch.int16).cpu().numpy().view(np.uint16)
             wb = orc.cast16(hb, True, args.mode)
@@ -506,8 +535,7 @@ def main():
             def bn_step():
                 hip.quantize_blocks_(xr, yr, 64, fmt, rm)
 
-            bn_step()
-            n_avg, _ = time_launches(bn_step, 10)
+            n_avg = time_batch(bn_step, launches=20, warm=3)
             verified["blocknorm_64_64Mi"] = same(yr[:HEAD], orc.cast_blocknorm(hx, args.mode, 64), nan_ok=True)
             extras["blocknorm_64_64Mi"] = {"ms": round(n_avg, 5), "GB/s": round(8 * xr.numel() / (n_avg * 1e-3) / 1e9, 1),
                                            "verified": verified["blocknorm_64_64Mi"]}
@@ -522,19 +550,36 @@ def main():
             si = torch.arange(5, M, 129, device=dev)[:64]
             sj = torch.arange(3, M, 127, device=dev)[:64]
             ha, hbm = ga[si].cpu().numpy(), gb_[:, sj].contiguous().cpu().numpy()
-            for name, variant, peak, fused in (("gemm_8192_mfma_fma_chain", 1, 157.3, True),
-                                               ("gemm_8192_valu_separate", 0, 78.6, False)):
+            # compute ceilings timed in this process, right before the legs they price: the bare MFMA pipe and the
+            # bare packed multiply + add stream (tools/ceilings.hip), 10 untimed launches then two events around 10
+            cc = {}
+            if C is not None:
+                sink = torch.zeros(1024, device=dev)
+                it_m, it_v, blk_m, blk_v = 2000, 4000, 512, 1024
+                cm = time_batch(lambda: C.ceil_mfma(sink.data_ptr(), it_m, blk_m, stream), launches=10, warm=10)
+                cv = time_batch(lambda: C.ceil_valu(sink.data_ptr(), it_v, blk_v, stream), launches=10, warm=10)
+                cc["mfma_f32"] = round(blk_m * 4 * it_m * 64.0 * 4096.0 / (cm * 1e-3) / 1e12, 2)
+                cc["valu_pk_f32"] = round(blk_v * 256.0 * it_v * 4 * 16 * 2 * 2 / (cv * 1e-3) / 1e12, 2)
+                extras.setdefault("ceilings", {})["TFLOP/s"] = dict(
+                    cc, how="bare v_mfma_f32_32x32x2_f32 chains (4 per wave, 2 waves per SIMD) / bare v_pk_mul_f32 + "
+                            "v_pk_add_f32 chains (16 per lane, 4 waves per SIMD), no memory traffic; same process, "
+                            "10 untimed launches then two events around 10")
+            for name, variant, peak, fused, bare in (("gemm_8192_mfma_fma_chain", 1, 157.3, True, "mfma_f32"),
+                                                     ("gemm_8192_valu_separate", 0, 78.6, False, "valu_pk_f32")):
                 def gstep(variant=variant):
                     hip.gemm_(gc, ga, gb_, 1.0, False, False, variant)
 
-                gstep()
-                g_avg, _ = time_launches(gstep, 5)
+                g_avg = time_batch(gstep, launches=10, warm=10)
+                _a, g_min = time_launches(gstep, 5)
                 gc.zero_()
                 gstep()
                 verified[name] = same(gc[si][:, sj].contiguous(), orc.gemm(ha, hbm, 1.0, fused=fused))
                 tf = 2.0 * M ** 3 / (g_avg * 1e-3) / 1e12
-                extras[name] = {"ms": round(g_avg, 4), "TFLOP/s": round(tf, 2), "peak": peak,
-                                "frac": round(tf / peak, 4), "verified": verified[name]}
+                extras[name] = {"ms": round(g_avg, 4), "min_ms": round(g_min, 4), "TFLOP/s": round(tf, 2), "peak": peak,
+                                "frac": round(tf / peak, 4),
+                                "frac_of_bare_pipe": round(tf / cc[bare], 4) if bare in cc else None,
+                                "timing": "10 untimed launches, then two HIP events around 10; min from 5 more, one event each",
+                                "verified": verified[name]}
             del ga, gb_, gc
 
             # cmodel convolution: ResNet-50's 3x3, 64 -> 64 channels, 56 x 56, batch 32
@@ -634,7 +679,9 @@ def main():
                        "sharding": "dp%d: contiguous shards, no collective on the unscaled path" % world},
             "hbm_GB/s_per_gpu": round(BYTES_PER_ELEM * n / (ms * 1e-3) / 1e9, 1),
             "hbm_frac_of_peak": round(BYTES_PER_ELEM * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            # the second per-GPU rate: the per-tensor-scaled step (amax + all-reduce(max) of one word + cast, 12 B/elem)
+            "scaled_step": extras.get("scaled_per_tensor"), "extras": extras,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

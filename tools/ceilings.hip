@@ -36,9 +36,66 @@ __global__ __launch_bounds__(BLOCK) void k_copy(const u32x4 *in, u32x4 *out, uin
   store_stream(out + i, __builtin_nontemporal_load(&in[i]));
 }
 
+// Compute ceilings for the c-model GEMM legs, timed in the bench process like the streams above:
+//   mfma : four independent v_mfma_f32_32x32x2_f32 accumulator chains per wave (the GEMM kernel's shape), no memory
+//          traffic -- what the fp32 MFMA pipe sustains at the clock this process gets;
+//   valu : sixteen independent packed chains per lane of a rounded product then a rounded sum (v_pk_mul_f32 +
+//          v_pk_add_f32, built with -ffp-contract=off) -- the separate-rounding GEMM's instruction mix, nothing else.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_mfma(float *out, int iters, float a0, float b0) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; i++)
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  const float a = a0 + threadIdx.x, b = b0;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; i++)
+    for (int r = 0; r < 16; r++) s += acc[i][r];
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_valu(float *out, int iters, float a0) {
+  f32x2 acc[16];
+  for (int i = 0; i < 16; i++) acc[i] = f32x2{1.0f + (float)i, 0.5f + (float)threadIdx.x};
+  const f32x2 a = {a0, -a0};
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const f32x2 p = a * acc[(i + 8) & 15];  // a product of its own (contraction is off), never loop-invariant
+        acc[i] = acc[i] + p;
+      }
+    }
+  }
+  f32x2 s = {0.f, 0.f};
+  for (int i = 0; i < 16; i++) s = s + acc[i];
+  if (s[0] + s[1] == 12345.678f) out[threadIdx.x] = s[0];
+}
+
 static int done(void) { return (int)hipGetLastError(); }
 
 extern "C" {
+// flop of one launch: blocks * 4 waves * iters * 64 MFMAs * 4096
+int ceil_mfma(void *out, int iters, int blocks, void *stream) {
+  if (out == nullptr || iters <= 0 || blocks <= 0) return -1;
+  hipLaunchKernelGGL(k_mfma, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float *)out, iters, 1.0f, 0.5f);
+  return done();
+}
+// flop of one launch: blocks * 256 lanes * iters * 4 * 16 chains * 2 elements * 2
+int ceil_valu(void *out, int iters, int blocks, void *stream) {
+  if (out == nullptr || iters <= 0 || blocks <= 0) return -1;
+  hipLaunchKernelGGL(k_valu, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float *)out, iters, 1e-9f);
+  return done();
+}
 int ceil_read(const void *in, void *sink, uint64_t nvec, void *stream) {
   if (nvec == 0 || nvec > (1ull << 38)) return -1;
   hipLaunchKernelGGL(k_read, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
