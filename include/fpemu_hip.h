@@ -195,7 +195,9 @@ int fpemu_quantize_per_tensor_ws(const void *in, void *out, uint64_t n, int dtyp
  * interfaces -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The
  * scratch (amax word + per-block maxima) is a 1280-byte __device__ array inside the library, one copy per
  * GPU, held until the process ends; its address is looked up once per device on the first call there
- * (the stream's device must be the current device, as for every entry point).  Results are bit-identical to
+ * (the stream's device must be the current device, as for every entry point).  A device's FIRST call must therefore
+ * be made outside stream capture (hipGetSymbolAddress is not a capturable call): warm the entry point up once per
+ * device before capturing graphs that contain it.  Results are bit-identical to
  * fpemu_quantize_per_tensor_ws with a 257-word workspace.
  *   amax_out : optional caller-owned device word that receives the amax bit pattern (NULL: not reported);
  *   n        : at most FPEMU_STATIC_MAX_ELEMS, else FPEMU_EINVAL (nothing is enqueued).

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+import orc
 from _util import assert_bits_equal, mixed_inputs
 
 pytestmark = pytest.mark.gpu
@@ -58,6 +59,10 @@ def test_static_equals_ws_two_calls_second_smaller(fmt, rm, flt_max):
         assert_bits_equal(got, want, "static vs ws, n=%d" % n)
         assert w_static == w_ws, (n, hex(w_static), hex(w_ws))
         assert w_ws == int(np.abs(x).max().view(np.uint32)), n
+        # and against the oracle itself (seed 11, call offset 5 as passed above), not only the sibling entry point
+        mode = "E4M3_RNE" if (fmt, rm) == (E4M3, RNE) else "E5M2_STOCHASTIC"
+        scale = orc.scale_from_amax(orc.amax(x), flt_max)
+        assert_bits_equal(got, orc.cast(x, mode, scale=scale, seed=11, offset=5), "static vs oracle, n=%d" % n)
 
 
 def test_static_without_amax_word_and_16bit_storage():
