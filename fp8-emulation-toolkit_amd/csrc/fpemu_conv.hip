@@ -40,7 +40,7 @@ extern "C" int fpemu_gemm_chain_start_launch_(float *C, const float *A, const fl
                                               int variant, int64_t batch, int64_t stride_a, int64_t stride_b,
                                               int64_t stride_c, int64_t k_segments, int64_t kseg_stride_a,
                                               int64_t kseg_stride_b, int start, const float *init, int64_t nstore,
-                                              void *stream);
+                                              uint32_t *amax, void *stream);
 
 namespace {
 
@@ -739,7 +739,7 @@ int64_t implicit_floats(int64_t imgs, int64_t chans, int64_t Hp, int64_t Wp, int
 
 extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float *xp, const float *bias, int64_t batch,
                                        int64_t M, int64_t cblocks, int64_t R, int64_t S, int64_t plane, int64_t Wp,
-                                       int64_t OH, int64_t OW, int reverse, void *stream);
+                                       int64_t OH, int64_t OW, int reverse, uint32_t *amax, void *stream);
 extern "C" int fpemu_gemm_conv_tile_(int64_t M, int64_t nvalid, int64_t batch);
 
 namespace {
@@ -751,7 +751,7 @@ namespace {
 int implicit_conv(const char *who, float *out, const float *src, const float *Wm, const float *bias, int64_t N,
                   int64_t chans, int64_t Hs, int64_t Ws, int64_t M, int64_t R, int64_t S, int64_t ph, int64_t pw,
                   int64_t OH, int64_t OW, int reverse, float *xp, int64_t xp_floats, hipStream_t s, int pack,
-                  const PackJob &job) {
+                  const PackJob &job, uint32_t *amax = nullptr) {
   // pack: 1 / 2 = the weights are not packed yet (forward / backward-data layout); done in the first launch here
   const int64_t Hp = Hs + 2 * ph, Wp = Ws + 2 * pw;
   const int64_t wtotal = pack == 1 ? job.g.K * job.g.C * job.g.R * job.g.S : pack == 2 ? job.g.C * job.g.K * job.g.R * job.g.S : 0;
@@ -763,7 +763,7 @@ int implicit_conv(const char *who, float *out, const float *src, const float *Wm
   if (ph == 0 && pw == 0 && R == 1 && S == 1 && N <= 65535 && (OH * Wp) % fpemu_gemm_conv_tile_(M, OH * Wp, N) == 0) {
     pack_alone();
     CHECK_LAUNCH(who);
-    const int rc = fpemu_gemm_conv_launch_(out, Wm, src, bias, N, M, chans / 64, R, S, Hp * Wp, Wp, OH, OW, reverse, (void *)s);
+    const int rc = fpemu_gemm_conv_launch_(out, Wm, src, bias, N, M, chans / 64, R, S, Hp * Wp, Wp, OH, OW, reverse, amax, (void *)s);
     if (rc != 0) return fail(who, rc, hipGetErrorString((hipError_t)rc));
     return FPEMU_OK;
   }
@@ -780,7 +780,7 @@ int implicit_conv(const char *who, float *out, const float *src, const float *Wm
                        job);
     CHECK_LAUNCH(who);
     const int rc = fpemu_gemm_conv_launch_(out + n0 * M * OH * OW, Wm, xp, bias, nb, M, chans / 64, R, S, Hp * Wp, Wp,
-                                           OH, OW, reverse, (void *)s);
+                                           OH, OW, reverse, amax, (void *)s);
     if (rc != 0) return fail(who, rc, hipGetErrorString((hipError_t)rc));
   }
   return FPEMU_OK;
@@ -810,10 +810,9 @@ uint64_t fpemu_conv2d_workspace_bytes(int kind, int64_t N, int64_t C, int64_t H,
   return (uint64_t)(wf + imgs * per + 128 + R * (W + 2 * pad + R) + S + 4) * 4u;
 }
 
-int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float *bias, int64_t N, int64_t C,
-                        int64_t H, int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad,
-                        int variant, void *ws, uint64_t ws_bytes, void *stream) {
-  const char *who = "fpemu_conv2d_fp_f32";
+static int conv2d_fp_impl(const char *who, float *out, const float *in, const float *w, const float *bias, int64_t N,
+                          int64_t C, int64_t H, int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                          int variant, void *ws, uint64_t ws_bytes, uint32_t *amax, void *stream) {
   Geo g;
   int rc = make_geo(who, g, N, C, H, W, K, R, S, stride, pad);
   if (rc != FPEMU_OK) return rc;
@@ -829,7 +828,7 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
   const int64_t P = g.OH * g.OW;
   if (FPEMU_CONV_IMPLICIT && variant == 1 && stride == 1 && C % 64 == 0 && K % 64 == 0) {
     rc = implicit_conv(who, out, in, Wm, bias, N, C, H, W, K, R, S, pad, pad, g.OH, g.OW, 0, cols,
-                       (int64_t)(ws_bytes / 4) - wf, s, 1, PackJob{w, Wm, g});
+                       (int64_t)(ws_bytes / 4) - wf, s, 1, PackJob{w, Wm, g}, amax);
     if (rc != 1) return rc;  // 1: workspace too small for the padded planes (nothing launched) -> the gathered form below
   }
   if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
@@ -846,10 +845,26 @@ int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float
                        dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * kp, (int)kp, (int)Pp);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_start_launch_(out + n0 * K * P, Wm, cols, K, Pp, kp, kp, Pp, P, 0, 0, variant, nb, 0, kp * Pp,
-                                        K * P, 1, 0, 0, start, bias, Pp != P ? P : 0, stream);
+                                        K * P, 1, 0, 0, start, bias, Pp != P ? P : 0, amax, stream);
     if (rc != FPEMU_OK) return rc;
   }
   return FPEMU_OK;
+}
+
+int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float *bias, int64_t N, int64_t C,
+                        int64_t H, int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                        int variant, void *ws, uint64_t ws_bytes, void *stream) {
+  return conv2d_fp_impl("fpemu_conv2d_fp_f32", out, in, w, bias, N, C, H, W, K, R, S, stride, pad, variant, ws, ws_bytes,
+                        nullptr, stream);
+}
+
+int fpemu_conv2d_fp_f32_amax(float *out, const float *in, const float *w, const float *bias, int64_t N, int64_t C,
+                             int64_t H, int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                             int variant, void *ws, uint64_t ws_bytes, uint32_t *amax_bits, void *stream) {
+  const char *who = "fpemu_conv2d_fp_f32_amax";
+  if (amax_bits == nullptr) return fail(who, FPEMU_EINVAL, "null amax word");
+  if ((uintptr_t)amax_bits % 4u) return fail(who, FPEMU_EALIGN, "amax word not 4-byte aligned");
+  return conv2d_fp_impl(who, out, in, w, bias, N, C, H, W, K, R, S, stride, pad, variant, ws, ws_bytes, amax_bits, stream);
 }
 
 int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N, int64_t C, int64_t H,
@@ -924,7 +939,7 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
                            dim3(NT), 0, s, gout + n0 * K * P, gath, g, ph, nb * krs_p);
         CHECK_LAUNCH(who);
         rc = fpemu_gemm_chain_start_launch_(plane, wph[p], gath, C, ph.pitch, krs_p, krs_p, ph.pitch, ph.pitch, 0, 0,
-                                            variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3, nullptr, 0, stream);
+                                            variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3, nullptr, 0, nullptr, stream);
         if (rc != FPEMU_OK) return rc;
         tb.plane[p] = plane; tb.pitch[p] = ph.pitch; tb.Wh[p] = ph.Wh;
         plane += nb * C * ph.pitch;
@@ -944,7 +959,7 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
                        dim3(NT), 0, s, gout + n0 * K * P, cols, g, nb * krs);
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_start_launch_(gin + n0 * C * HW, Wm, cols, C, HW, krs, krs, HW, HW, 0, 0, variant, nb, 0,
-                                        krs * HW, C * HW, 1, 0, 0, 3, nullptr, 0, stream);   // chains start at +0
+                                        krs * HW, C * HW, 1, 0, 0, 3, nullptr, 0, nullptr, stream);   // chains start at +0
     if (rc != FPEMU_OK) return rc;
   }
   return FPEMU_OK;
@@ -986,7 +1001,7 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
     // one chain across the chunk's images in ONE launch: k segments = images (chunks follow in order)
     // (the first chunk's chains start at +0, the later ones where the chunk before left them)
     rc = fpemu_gemm_chain_start_launch_(Gm, ga, cols, K, crs, Pp, Pp, Pp, crs, 0, 1, variant, 1, 0, 0, 0, nb,
-                                        K * Pp, crs * Pp, n0 == 0 ? 3 : 0, nullptr, 0, stream);
+                                        K * Pp, crs * Pp, n0 == 0 ? 3 : 0, nullptr, 0, nullptr, stream);
     if (rc != FPEMU_OK) return rc;
   }
   hipLaunchKernelGGL(unpack_gw, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, gw, g);

@@ -221,7 +221,25 @@ struct Batch {
   // Columns >= nstore (when nonzero) are computed but not stored: B is padded with zero columns to whole tiles so that
   // every load is unchecked, while C keeps its own row length (the convolution's forward result: rows of OH*OW).
   int nstore;
+  // Non-null: the kernel folds the bit patterns of |every value it stores to C| into this device word (unsigned max; a NaN
+  // wins, as torch.max) -- the amax pass of a per-tensor quantisation of C that follows (quantize_module_output,
+  // reference qutils.py:607-609) is then already done: the values are in registers here.  The caller zeroes the word.
+  uint32_t *amax;
 };
+
+__device__ __forceinline__ uint32_t abs_bits(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
+__device__ __forceinline__ uint32_t max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+// One conditional atomic per wave: the running maximum only grows, so a wave whose maximum does not beat the value
+// already published skips it (a stale read only costs a redundant atomic).  Reached by whole waves only.
+__device__ __forceinline__ void publish_amax(uint32_t *word, uint32_t m) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = max_u32(m, (uint32_t)__shfl_xor((int)m, off, 64));
+  if ((threadIdx.x & 63u) == 0u) {
+    const uint32_t seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m > seen) __hip_atomic_fetch_max(word, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 __device__ __forceinline__ float chain_start(const Batch &bt, const float *C, int64_t idx, int row) {
   if (bt.start == 0) return C[idx];
@@ -326,6 +344,7 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
   }
 
   const int M = A.R, N = B.R;
+  uint32_t mx = 0u;  // max |stored value| (Batch.amax)
 #pragma unroll
   for (int ih = 0; ih < H; ih++)
 #pragma unroll
@@ -339,19 +358,31 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
         if constexpr (CHAIN) {
 #pragma unroll
           for (int jj = 0; jj < 4; jj++)
-            if (c + jj < N && (bt.nstore == 0 || c + jj < bt.nstore)) dst[jj] = acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1];
+            if (c + jj < N && (bt.nstore == 0 || c + jj < bt.nstore)) {
+              const float o = acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1];
+              dst[jj] = o;
+              mx = max_u32(mx, abs_bits(o));
+            }
         } else if (c_vec && c + 3 < N) {
           f32x4 ci = *reinterpret_cast<const f32x4 *>(dst), o;
 #pragma unroll
-          for (int jj = 0; jj < 4; jj++) o[jj] = epilogue(ci[jj], acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1], alpha, beta);
+          for (int jj = 0; jj < 4; jj++) {
+            o[jj] = epilogue(ci[jj], acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1], alpha, beta);
+            mx = max_u32(mx, abs_bits(o[jj]));
+          }
           *reinterpret_cast<f32x4 *>(dst) = o;
         } else {
 #pragma unroll
           for (int jj = 0; jj < 4; jj++)
-            if (c + jj < N) dst[jj] = epilogue(dst[jj], acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1], alpha, beta);
+            if (c + jj < N) {
+              const float o = epilogue(dst[jj], acc2[ih * 4 + ii][(jh * 4 + jj) >> 1][jj & 1], alpha, beta);
+              dst[jj] = o;
+              mx = max_u32(mx, abs_bits(o));
+            }
         }
       }
     }
+  if (bt.amax != nullptr) publish_amax(bt.amax, mx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -669,6 +700,7 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
 
   CONV_STAMP(ts2);  // k loop done
   [[maybe_unused]] const int M = A.R, N = B.R;
+  uint32_t mx = 0u;  // max |stored value| (Batch.amax)
   if constexpr (CONV) {
 #pragma unroll
     for (int j = 0; j < TW; j++) {
@@ -682,6 +714,7 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
           for (int r = 0; r < 16; r++) {
             const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             dst[(int64_t)row * cm.P] = acc[i][j][r];
+            mx = max_u32(mx, abs_bits(acc[i][j][r]));
           }
       }
     }
@@ -703,7 +736,10 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
         for (int r = 0; r < 16; r++) {
           const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int col = n0 + wn + j * 32 + li;
-          if ((FULL || (row < M && col < N)) && (bt.nstore == 0 || col < bt.nstore)) C[(int64_t)row * ldc + col] = acc[i][j][r];
+          if ((FULL || (row < M && col < N)) && (bt.nstore == 0 || col < bt.nstore)) {
+            C[(int64_t)row * ldc + col] = acc[i][j][r];
+            mx = max_u32(mx, abs_bits(acc[i][j][r]));
+          }
         }
   } else {
     // per 32x32 MFMA tile: its 16 reads of C first (independent), then the 16 read-modify-writes -- one
@@ -723,11 +759,15 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
         for (int r = 0; r < 16; r++) {
           const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int col = n0 + wn + j * 32 + li;
-          if (FULL || (row < M && col < N))
-            C[(int64_t)row * ldc + col] = epilogue(cin[r], acc[i][j][r], alpha, beta);
+          if (FULL || (row < M && col < N)) {
+            const float o = epilogue(cin[r], acc[i][j][r], alpha, beta);
+            C[(int64_t)row * ldc + col] = o;
+            mx = max_u32(mx, abs_bits(o));
+          }
         }
       }
   }
+  if (bt.amax != nullptr) publish_amax(bt.amax, mx);
 }
 
 template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL, int TW>
@@ -996,15 +1036,18 @@ __global__ __launch_bounds__(NT) void gemm_mfma16_kernel(Operand A, Operand B, f
     tile_body(c1{}, std::false_type{}, it + 2 < total, cur.more());
   }
 
+  uint32_t mx = 0u;  // max |stored value| (Batch.amax)
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = m0 + wm + 4 * lk + r;
     if ((FULL || (row < M && col < N)) && (bt.nstore == 0 || col < bt.nstore)) {
       float *dst = C + (int64_t)row * ldc + col;
-      if constexpr (CHAIN) *dst = acc[r];
-      else *dst = epilogue(*dst, acc[r], alpha, beta);
+      const float o = CHAIN ? acc[r] : epilogue(*dst, acc[r], alpha, beta);
+      *dst = o;
+      mx = max_u32(mx, abs_bits(o));
     }
   }
+  if (bt.amax != nullptr) publish_amax(bt.amax, mx);
 }
 
 // The same problem with the work SPLIT BY WAVE (FPEMU_GEMM_WS, the default): the chain waves own the 16x16 chains and
@@ -1353,15 +1396,18 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
     tile(std::integral_constant<int, 1>{}, it + 1);
   }
   if (it < total) tile(std::integral_constant<int, 0>{}, it);
+  uint32_t mx = 0u;  // max |stored value| (Batch.amax)
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = m0 + wm + 4 * lk + r;
     if ((MODE == 2 || (row < M && col < N)) && (bt.nstore == 0 || col < bt.nstore)) {
       float *dst = C + (int64_t)row * ldc + col;
-      if constexpr (CHAIN) *dst = acc[r];
-      else *dst = epilogue(*dst, acc[r], alpha, beta);
+      const float o = CHAIN ? acc[r] : epilogue(*dst, acc[r], alpha, beta);
+      *dst = o;
+      mx = max_u32(mx, abs_bits(o));
     }
   }
+  if (bt.amax != nullptr) publish_amax(bt.amax, mx);
 #ifdef FPEMU_WS_TRACE
   if (g_ws_trace && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {  // loaders have long finished
     for (int i = threadIdx.x; i < 256 * 8; i += 64) g_ws_trace[i] = ws_stamps[i];
@@ -1523,7 +1569,7 @@ extern "C" int fpemu_gemm_conv_tile_(int64_t M, int64_t nvalid, int64_t batch) {
 
 extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float *xp, const float *bias, int64_t batch,
                                        int64_t M, int64_t cblocks, int64_t R, int64_t S, int64_t plane, int64_t Wp,
-                                       int64_t OH, int64_t OW, int reverse, void *stream) {
+                                       int64_t OH, int64_t OW, int reverse, uint32_t *amax, void *stream) {
   const int64_t nvalid = OH * Wp, crs = cblocks * 64 * R * S;
   const int tb = fpemu_gemm_conv_tile_(M, nvalid, batch);
   const int tiles_m = (int)(M / tb), tiles_n = (int)((nvalid + tb - 1) / tb);
@@ -1531,6 +1577,7 @@ extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float 
   a.p = Wm; a.ld = crs; a.R = (int)M; a.K = 64; a.vec = 1; a.pad = -0.0f;
   b.p = reverse ? xp + (S - 1) : xp; b.ld = plane; b.R = tiles_n * tb; b.K = 64; b.vec = 1; b.pad = 0.0f;
   Batch bt{0, cblocks * 64 * plane, M * OH * OW, 64, 64 * plane, (int)(cblocks * R * S)};
+  bt.amax = amax;
   ConvMap cm{bias, (int)S, (int)R, (int)Wp, reverse ? -1 : 1, (int)OW, (int)(OH * OW), (int)nvalid};
   const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)batch);
   if (tb == 128)
@@ -1545,6 +1592,19 @@ extern "C" int fpemu_gemm_f32(float *C, const float *A, const float *B, int64_t 
                               int b_trans, int variant, void *stream) {
   return launch_gemm("fpemu_gemm_f32", C, A, B, M, N, K, lda, ldb, ldc, alpha, a_trans, b_trans, variant, false,
                      1, Batch{0, 0, 0, 0, 0, 1}, stream);
+}
+
+extern "C" int fpemu_gemm_f32_amax(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                                   int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans,
+                                   int b_trans, int variant, uint32_t *amax_bits, void *stream) {
+  if (amax_bits == nullptr || ((uintptr_t)amax_bits % 4u)) {
+    fpemu_set_error_("fpemu_gemm_f32_amax: null or unaligned amax word");
+    return amax_bits == nullptr ? FPEMU_EINVAL : FPEMU_EALIGN;
+  }
+  Batch bt{0, 0, 0, 0, 0, 1};
+  bt.amax = amax_bits;
+  return launch_gemm("fpemu_gemm_f32_amax", C, A, B, M, N, K, lda, ldb, ldc, alpha, a_trans, b_trans, variant, false,
+                     1, bt, stream);
 }
 
 extern "C" int fpemu_gemm_chain_f32(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
@@ -1569,13 +1629,14 @@ extern "C" int fpemu_gemm_chain_start_launch_(float *C, const float *A, const fl
                                               int variant, int64_t batch, int64_t stride_a, int64_t stride_b,
                                               int64_t stride_c, int64_t k_segments, int64_t kseg_stride_a,
                                               int64_t kseg_stride_b, int start, const float *init, int64_t nstore,
-                                              void *stream) {
+                                              uint32_t *amax, void *stream) {
   if (k_segments < 1 || k_segments > 0x7FFFFFFF || start < 0 || start > 3 || ((start == 1 || start == 2) && !init) ||
       nstore < 0 || nstore > N || (nstore != 0 && start == 0)) {
     fpemu_set_error_("fpemu_gemm_chain_start_launch_: bad k_segments / start");
     return FPEMU_EINVAL;
   }
   return launch_gemm("fpemu_gemm_chain_f32", C, A, B, M, N, K, lda, ldb, ldc, 1.0f, a_trans, b_trans, variant, true, batch,
-                     Batch{stride_a, stride_b, stride_c, kseg_stride_a, kseg_stride_b, (int)k_segments, start, init, (int)nstore},
+                     Batch{stride_a, stride_b, stride_c, kseg_stride_a, kseg_stride_b, (int)k_segments, start, init, (int)nstore,
+                           amax},
                      stream);
 }

@@ -16,6 +16,12 @@ stride and padding, no dilation, no groups, as the reference.
 Divergences: backward zero-initialises the gradient buffers (the reference accumulates into
 torch.empty_like, simple.py:163-164); unsupported conv arguments raise ValueError instead of sys.exit;
 the batch is convolved image by image also when C or K < 64 (the reference's packing collapses it).
+
+Output maxima.  With `collect_output_amax(True)` (the module hooks switch it on around a hooked module whose output
+is quantised per tensor) `mm` / `matmul` / `conv2d` run the kernels' `_amax` forms: the epilogue folds max |output|
+into a device word and leaves it with the binding (`_binding.note_amax`), so the quantisation of that output
+(quantize_module_output, reference qutils.py:607-609) is one 8-byte-per-element cast instead of an amax pass plus
+the cast.  Same bits either way.  `addmm` adds beta * input after the product, so its maximum is not known.
 """
 import warnings
 
@@ -29,6 +35,18 @@ fallback_matmul = torch.matmul
 fallback_mm = torch.mm
 
 _variant = _hip.GEMM_FMA
+_collect = False
+
+
+def collect_output_amax(on):
+    """Switch the epilogue amax of mm / matmul / conv2d on or off; returns the previous setting."""
+    global _collect
+    prev, _collect = _collect, bool(on)
+    return prev
+
+
+def _amax_word(like):
+    return torch.zeros(1, dtype=torch.int32, device=like.device) if _collect else None
 
 
 def set_accumulation(kind):
@@ -52,8 +70,8 @@ def is_transposed(input):
     return input.contiguous(), False
 
 
-def _gemm(out, a, b, alpha, a_trans, b_trans):
-    return _hip.gemm_(out, a, b, alpha, a_trans, b_trans, _variant)
+def _gemm(out, a, b, alpha, a_trans, b_trans, amax=None):
+    return _hip.gemm_(out, a, b, alpha, a_trans, b_trans, _variant, amax=amax)
 
 
 def _on_gpu_f32(*ts):
@@ -89,8 +107,13 @@ def mm(input, mat2, out=None):
         return _decline("mm", fallback_mm, (tuple(input.size()), tuple(mat2.size())), input, mat2, out=out)
     a_mat, a_trans = is_transposed(input)
     b_mat, b_trans = is_transposed(mat2)
-    output = out if out is not None else _fresh(input.size(0), mat2.size(1), input)
-    return SimpleMatmul.apply(output, a_mat, b_mat, 1.0, a_trans, b_trans)
+    fresh = out is None
+    output = _fresh(input.size(0), mat2.size(1), input) if fresh else out
+    word = _amax_word(output) if fresh and output.is_contiguous() else None   # (a given `out` may hold other values)
+    res = SimpleMatmul.apply(output, a_mat, b_mat, 1.0, a_trans, b_trans, word)
+    if word is not None:
+        _hip.note_amax(res, word)
+    return res
 
 
 def matmul(input, other, out=None):
@@ -101,11 +124,15 @@ def matmul(input, other, out=None):
         b_mat, b_trans = is_transposed(other)
         outs = out if out is not None else torch.zeros([input.size(0), input.size(1), other.size(1)],
                                                        device=input.device)
+        word = _amax_word(outs) if out is None else None   # every slice folds its maximum into the one word
         res = []
         for i in range(input.size(0)):
             a_mat, a_trans = is_transposed(input[i])
-            res.append(SimpleMatmul.apply(outs[i], a_mat, b_mat, 1.0, a_trans, b_trans))
-        return torch.stack(res)
+            res.append(SimpleMatmul.apply(outs[i], a_mat, b_mat, 1.0, a_trans, b_trans, word))
+        stacked = torch.stack(res)
+        if word is not None:
+            _hip.note_amax(stacked, word)   # a copy of the slices: the same values, the same maximum
+        return stacked
     return _decline("matmul", fallback_matmul, (tuple(input.size()), tuple(other.size())), input, other, out=out)
 
 
@@ -128,8 +155,12 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     h_out = (H + 2 * padding[0] - dilation[0] * (R - 1) - 1) // stride[0] + 1
     w_out = (W + 2 * padding[1] - dilation[1] * (S - 1) - 1) // stride[1] + 1
     output = torch.empty([N, K, h_out, w_out], device=input.device)
-    return SimpleConv2dFunction.apply(output, input.contiguous(), weight.contiguous(), bias, stride, padding,
-                                      dilation, groups)
+    word = _amax_word(output)
+    res = SimpleConv2dFunction.apply(output, input.contiguous(), weight.contiguous(), bias, stride, padding,
+                                     dilation, groups, word)
+    if word is not None:
+        _hip.note_amax(res, word)
+    return res
 
 
 def _grads(grad_output, mat1, mat2, alpha, a_trans, b_trans):
@@ -166,10 +197,10 @@ class SimpleAddmm(Function):
 
 class SimpleMatmul(Function):
     @staticmethod
-    def forward(ctx, output, mat1, mat2, alpha, a_trans, b_trans):
+    def forward(ctx, output, mat1, mat2, alpha, a_trans, b_trans, amax=None):
         ctx.save_for_backward(mat1, mat2)
         ctx.a_trans, ctx.b_trans, ctx.alpha = a_trans, b_trans, alpha
-        _gemm(output, mat1, mat2, alpha, a_trans, b_trans)
+        _gemm(output, mat1, mat2, alpha, a_trans, b_trans, amax)
         ctx.mark_dirty(output)
         return output
 
@@ -177,16 +208,16 @@ class SimpleMatmul(Function):
     def backward(ctx, grad_output):
         mat1, mat2 = ctx.saved_tensors
         g1, g2 = _grads(grad_output, mat1, mat2, ctx.alpha, ctx.a_trans, ctx.b_trans)
-        return grad_output, g1, g2, None, None, None
+        return grad_output, g1, g2, None, None, None, None
 
 
 class SimpleConv2dFunction(Function):
     @staticmethod
-    def forward(ctx, output, inputs, weights, bias, stride, padding, dilation, groups):
+    def forward(ctx, output, inputs, weights, bias, stride, padding, dilation, groups, amax=None):
         ctx.save_for_backward(inputs, weights)
         ctx.stride, ctx.padding = stride, padding
         _hip.conv2d_fp_(output, inputs, weights, None if bias is None else bias.contiguous(), stride[0], padding[0],
-                        _variant)
+                        _variant, amax=amax)
         ctx.mark_dirty(output)
         return output
 
@@ -198,4 +229,4 @@ class SimpleConv2dFunction(Function):
         grad_wts = torch.empty_like(weights)
         _hip.conv2d_bp_(grad_inp, grad_output, weights, ctx.stride[0], ctx.padding[0], _variant)
         _hip.conv2d_wu_(grad_wts, grad_output, inputs, ctx.stride[0], ctx.padding[0], _variant)
-        return grad_output, grad_inp, grad_wts, None, None, None, None, None
+        return grad_output, grad_inp, grad_wts, None, None, None, None, None, None

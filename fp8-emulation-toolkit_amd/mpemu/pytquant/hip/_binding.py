@@ -71,12 +71,16 @@ def lib():
         i64 = ctypes.c_int64
         L.fpemu_gemm_f32.restype = i32
         L.fpemu_gemm_f32.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, i32, i32, i32, vp]
+        L.fpemu_gemm_f32_amax.restype = i32
+        L.fpemu_gemm_f32_amax.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, i32, i32, i32, vp, vp]
         L.fpemu_gemm_chain_f32.restype = i32
         L.fpemu_gemm_chain_f32.argtypes = [vp, vp, vp] + [i64] * 6 + [i32, i32, i32] + [i64] * 7 + [vp]
         L.fpemu_conv2d_workspace_bytes.restype = u64
         L.fpemu_conv2d_workspace_bytes.argtypes = [i32] + [i64] * 9
         L.fpemu_conv2d_fp_f32.restype = i32
         L.fpemu_conv2d_fp_f32.argtypes = [vp, vp, vp, vp] + [i64] * 9 + [i32, vp, u64, vp]
+        L.fpemu_conv2d_fp_f32_amax.restype = i32
+        L.fpemu_conv2d_fp_f32_amax.argtypes = [vp, vp, vp, vp] + [i64] * 9 + [i32, vp, u64, vp, vp]
         for nm in ("fpemu_conv2d_bp_f32", "fpemu_conv2d_wu_f32"):
             f = getattr(L, nm)
             f.restype = i32
@@ -97,7 +101,7 @@ def lib():
         L.fpemu_amax_rows.argtypes = [vp, u64, u64, i32, vp, vp]
         L.fpemu_cast_rows_amax.restype = i32
         L.fpemu_cast_rows_amax.argtypes = [vp, vp, u64, u64, i32, i32, i32, vp, f32, i32, u64, u64, u64, vp]
-        if L.fpemu_abi_version() != 9:
+        if L.fpemu_abi_version() != 10:
             raise ImportError("libfpemu_hip.so: ABI version mismatch")
         _lib = L
     return _lib
@@ -587,12 +591,43 @@ def quantize_blocks_(src, dst, block_size, fmt, rmode):
 GEMM_SEPARATE, GEMM_FMA = 0, 1
 
 
-def gemm_(C, A, B, alpha=1.0, a_trans=False, b_trans=False, variant=GEMM_FMA):
+# ---- known output maxima ---------------------------------------------------------------------
+# A c-model op whose epilogue folded max |output| into a device word leaves (output, word) here; the per-tensor
+# quantisation of that very tensor right afterwards (quantize_module_output, reference qutils.py:607-609) then skips
+# its amax pass.  ONE slot, holding the tensor itself: while it is held its address cannot be handed to another
+# tensor, and any in-place change since bumps _version -- a stale entry can never match.
+_known = None
+
+
+def note_amax(t, word):
+    """`word` (int32[1] on t's device) holds bits(max |t|) in stream order; t is as the producer left it."""
+    global _known
+    _known = (t, t.data_ptr(), t.numel(), t._version, word)
+
+
+def take_amax(t):
+    """The amax word of t if the last c-model op produced exactly this tensor (same storage, size, dtype, version),
+    else None.  Either way the slot is emptied."""
+    global _known
+    k, _known = _known, None
+    if (k is not None and k[1] == t.data_ptr() and k[2] == t.numel() and k[3] == t._version
+            and k[0].dtype == t.dtype and t.is_contiguous()):
+        return k[4]
+    return None
+
+
+def forget_amax():
+    global _known
+    _known = None
+
+
+def gemm_(C, A, B, alpha=1.0, a_trans=False, b_trans=False, variant=GEMM_FMA, amax=None):
     """C += alpha * op(A) @ op(B) with the cmodel's k-ascending fp32 accumulation chain; the call
     simple_gemm_dev.gemm(C, A, B, alpha, a_trans, b_trans) of the reference
     (mpemu/cmodel/simple/simple_gemm.cpp:45-67).  A is stored [K, M] when a_trans, B [N, K] when
     b_trans.  variant: GEMM_FMA (fmaf chain on MFMA) or GEMM_SEPARATE (multiply and add rounded
-    separately, VALU)."""
+    separately, VALU).  amax: int32[1] on C's device (zeroed by the caller): receives
+    max(amax, bits(max |C|)) of the final C from the kernel's epilogue (fpemu_gemm_f32_amax)."""
     for t, what in ((C, "C"), (A, "A"), (B, "B")):
         _require_device(t, what)
         if t.dtype != torch.float32 or t.dim() != 2:
@@ -604,10 +639,22 @@ def gemm_(C, A, B, alpha=1.0, a_trans=False, b_trans=False, variant=GEMM_FMA):
         raise ValueError("fpemu gemm: shapes do not match: C %s, A %s (trans=%s), B %s (trans=%s)" % (
             tuple(C.shape), tuple(A.shape), a_trans, tuple(B.shape), b_trans))
     with _range("cmodel::simple_gemm"), _on_device(C):
-        _check(lib().fpemu_gemm_f32(C.data_ptr(), A.data_ptr(), B.data_ptr(), M, N, K, A.shape[1], B.shape[1],
-                                    C.shape[1], float(alpha), int(bool(a_trans)), int(bool(b_trans)),
-                                    int(variant), _stream(C)))
+        if amax is None:
+            _check(lib().fpemu_gemm_f32(C.data_ptr(), A.data_ptr(), B.data_ptr(), M, N, K, A.shape[1], B.shape[1],
+                                        C.shape[1], float(alpha), int(bool(a_trans)), int(bool(b_trans)),
+                                        int(variant), _stream(C)))
+        else:
+            _require_amax_word(amax, C)
+            _check(lib().fpemu_gemm_f32_amax(C.data_ptr(), A.data_ptr(), B.data_ptr(), M, N, K, A.shape[1], B.shape[1],
+                                             C.shape[1], float(alpha), int(bool(a_trans)), int(bool(b_trans)),
+                                             int(variant), amax.data_ptr(), _stream(C)))
     return C
+
+
+def _require_amax_word(word, like):
+    if (not torch.is_tensor(word) or word.device != like.device or word.dtype != torch.int32 or word.numel() < 1
+            or not word.is_contiguous()):
+        raise ValueError("fpemu: amax must be a contiguous int32 tensor of at least one word on %s" % (like.device,))
 
 
 CONV_FP, CONV_BP, CONV_WU = 0, 1, 2
@@ -627,9 +674,9 @@ def _conv_check(ts):
             raise TypeError("fpemu conv2d: %s must be float32" % what)
 
 
-def conv2d_fp_(output, input, weight, bias, stride, padding, variant=GEMM_FMA):
+def conv2d_fp_(output, input, weight, bias, stride, padding, variant=GEMM_FMA, amax=None):
     """simple_conv2d_dev.conv2d_fp(output, input, weight, bias, stride, padding, 1, 1) of the reference
-    (cmodel/simple/simple_conv2d.cpp:44-69) on the GPU; output [N,K,OH,OW] is overwritten."""
+    (cmodel/simple/simple_conv2d.cpp:44-69) on the GPU; output [N,K,OH,OW] is overwritten.  amax: as gemm_."""
     _conv_check([(output, "output"), (input, "input"), (weight, "weight")] + ([(bias, "bias")] if bias is not None else []))
     N, C, H, W = input.shape
     K, C1, R, S = weight.shape
@@ -639,9 +686,15 @@ def conv2d_fp_(output, input, weight, bias, stride, padding, variant=GEMM_FMA):
         raise ValueError("fpemu conv2d_fp: shapes do not match")
     with _range("cmodel::simple_conv2d_fp"), _on_device(input):
         ws, nbytes = _conv_ws(CONV_FP, dims, input)
-        _check(lib().fpemu_conv2d_fp_f32(output.data_ptr(), input.data_ptr(), weight.data_ptr(),
-                                         None if bias is None else bias.data_ptr(), *dims, int(variant),
-                                         ws.data_ptr(), nbytes, _stream(input)))
+        if amax is None:
+            _check(lib().fpemu_conv2d_fp_f32(output.data_ptr(), input.data_ptr(), weight.data_ptr(),
+                                             None if bias is None else bias.data_ptr(), *dims, int(variant),
+                                             ws.data_ptr(), nbytes, _stream(input)))
+        else:
+            _require_amax_word(amax, output)
+            _check(lib().fpemu_conv2d_fp_f32_amax(output.data_ptr(), input.data_ptr(), weight.data_ptr(),
+                                                  None if bias is None else bias.data_ptr(), *dims, int(variant),
+                                                  ws.data_ptr(), nbytes, amax.data_ptr(), _stream(input)))
     return output
 
 

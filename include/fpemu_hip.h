@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FPEMU_ABI_VERSION 9
+#define FPEMU_ABI_VERSION 10
 
 /* Storage dtype of in/out buffers. */
 enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
@@ -277,6 +277,18 @@ int fpemu_gemm_f32(float *C, const float *A, const float *B, int64_t M, int64_t 
                    int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans,
                    int variant, void *stream);
 
+/* fpemu_gemm_f32 that also reports the maximum magnitude of what it wrote: *amax_bits = max(*amax_bits, bits(|C[i][j]|))
+ * over every element of the final C, as unsigned integers (= the float maximum; a NaN wins, as torch.max) -- the
+ * convention of fpemu_amax, so several calls may accumulate into one word that the caller zeroed first (the slices of
+ * a stacked matmul, reference simple.py:52-63).  The reference quantises a hooked module's output right after the
+ * patched matmul / conv (quantize_module_output, qutils.py:586-609: torch.max(abs(output)) then the cast); here the
+ * epilogue has the values in registers, so that amax pass over the output disappears and the per-tensor
+ * quantisation of the output is fpemu_cast_scaled(C, ..., amax_bits, ...) alone: 8 instead of 12 bytes per element.
+ * The matrix result is bit-identical to fpemu_gemm_f32. */
+int fpemu_gemm_f32_amax(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K, int64_t lda,
+                        int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans, int variant,
+                        uint32_t *amax_bits, void *stream);
+
 /* Chain-mode (and batched) form of the cmodel GEMM, the building block of the cmodel convolution: the
  * accumulators START at C's current values and C = acc (what MMEngine_avx2_ps does inside the
  * reference's conv kernels: load C, continue the k-ascending chain, store; simple_mm_engine.cpp:18-24),
@@ -308,6 +320,10 @@ uint64_t fpemu_conv2d_workspace_bytes(int kind, int64_t N, int64_t C, int64_t H,
 int fpemu_conv2d_fp_f32(float *out, const float *in, const float *w, const float *bias, int64_t N, int64_t C,
                         int64_t H, int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad,
                         int variant, void *ws, uint64_t ws_bytes, void *stream);
+/* fpemu_conv2d_fp_f32 that also folds max |out| into *amax_bits (see fpemu_gemm_f32_amax: same convention, same use). */
+int fpemu_conv2d_fp_f32_amax(float *out, const float *in, const float *w, const float *bias, int64_t N, int64_t C,
+                             int64_t H, int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                             int variant, void *ws, uint64_t ws_bytes, uint32_t *amax_bits, void *stream);
 int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N, int64_t C, int64_t H,
                         int64_t W, int64_t K, int64_t R, int64_t S, int64_t stride, int64_t pad, int variant,
                         void *ws, uint64_t ws_bytes, void *stream);

@@ -258,3 +258,69 @@ def test_hw_patch_simple_routes_conv_and_matmul_through_cmodel(hip):
     _, xi, wi, bi, yo = seen[0]
     want = orc.conv2d_fp(xi.cpu().numpy(), wi.cpu().numpy(), bi.cpu().numpy(), 1, 1, True)
     assert_bits_equal(yo.cpu().numpy(), want, "patched conv = c-model chain on the quantised operands")
+
+
+# ---- the forward convolution's output maximum (fpemu_conv2d_fp_f32_amax) ----
+@pytest.mark.parametrize("bname,variant,fused", VARIANTS)
+@pytest.mark.parametrize("case", [(4, 64, 14, 14, 64, 3, 3, 1, 1),      # implicit GEMM, padded planes (fma variant)
+                                  (3, 128, 9, 13, 64, 1, 1, 1, 0),      # implicit GEMM straight from the source planes
+                                  (40, 64, 28, 28, 256, 3, 3, 1, 1),    # 128 x 128 tiles
+                                  (2, 3, 32, 32, 64, 7, 7, 2, 3),       # gathered form, ragged rows (nstore)
+                                  (1, 64, 28, 28, 192, 3, 3, 2, 1),     # gathered, strided
+                                  (5, 1, 5, 5, 1, 5, 5, 1, 0)])         # one output per image
+def test_conv_fp_amax_epilogue(hip, bname, variant, fused, case):
+    """Same output bit for bit, and the word is bits(max |out|) over VALID outputs only (the implicit GEMM's garbage
+    columns and the gathered form's zero-padded columns are computed but never stored, and never counted)."""
+    N, C, H, W, K, R, S, st, pd = case
+    rng = np.random.default_rng(sum(case) + 1)
+    OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
+    x = _t(rng.standard_normal((N, C, H, W)).astype(np.float32))
+    w = _t((rng.standard_normal((K, C, R, S)) * 0.3).astype(np.float32))
+    b = _t(rng.standard_normal(K).astype(np.float32))
+    for bias in (b, None):
+        plain = torch.empty(N, K, OH, OW, device=DEV)
+        withmax = torch.empty(N, K, OH, OW, device=DEV)
+        word = torch.zeros(1, dtype=torch.int32, device=DEV)
+        hip.conv2d_fp_(plain, x, w, bias, st, pd, variant)
+        hip.conv2d_fp_(withmax, x, w, bias, st, pd, variant, amax=word)
+        assert torch.equal(plain.view(torch.int32), withmax.view(torch.int32))
+        assert int(word.item()) == int(np.float32(plain.abs().max().item()).view(np.uint32))
+
+
+def test_hooked_conv_output_quantised_from_the_epilogue_maximum(hip, monkeypatch):
+    """A hooked Conv2d with patch_ops / SIMPLE and a per-tensor output configuration (the hybrid training preset's
+    oact): the c-model convolution leaves max |out| with the binding and the output hook's quantize_tensor is the cast
+    alone.  Bits equal the run with the collection off, and the oracle's conv -> amax -> cast."""
+    from mpemu import qutils
+    from mpemu.cmodel import simple
+
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV)
+    x = torch.randn(2, 64, 12, 12, device=DEV)
+    qc = qutils.ModuleQuantConfig(wt_qconfig=qutils.TensorQuantConfig("e4m3", "rne", "per-tensor"),
+                                  iact_qconfig=qutils.TensorQuantConfig("e4m3", "rne", "per-tensor"),
+                                  oact_qconfig=qutils.TensorQuantConfig("e4m3", "rne", "per-tensor"), patch_ops=True)
+    qc.patch_impl = "SIMPLE"
+    cfg = {"": qc}
+    qutils.reset_quantization_setup(conv, cfg)
+    handles = qutils.add_quantization_hooks(conv, cfg)
+    w0 = conv.weight.data.clone()
+    calls = []
+    real = hip.cast_scaled_
+    monkeypatch.setattr(hip, "cast_scaled_", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    try:
+        with torch.no_grad():
+            y_fast = conv(x).clone()
+        assert calls == [1] and hip._known is None and simple._collect is False
+        conv.weight.data.copy_(w0)
+        monkeypatch.setattr(simple, "collect_output_amax", lambda on: False)   # collection off: the ordinary path
+        with torch.no_grad():
+            y_plain = conv(x).clone()
+        assert calls == [1]
+    finally:
+        for h in handles:
+            h.remove()
+    assert torch.equal(y_fast.view(torch.int32), y_plain.view(torch.int32))
+    q = lambda a: orc.cast(a, "E4M3_RNE", scale=orc.scale_from_amax(orc.amax(a), 448.0))
+    out = orc.conv2d_fp(q(x.cpu().numpy()), q(w0.cpu().numpy()), conv.bias.detach().cpu().numpy(), 1, 1, True)
+    assert_bits_equal(y_fast.cpu().numpy(), q(out), "hooked conv output")

@@ -9,7 +9,8 @@
   4 full rows against the sequential-k oracle (reference simple_gemm_impl.cpp:210-231,
   simple_mm_engine.cpp:13-27).
 * the emulated-FP8 GEMM pipeline: per-tensor E4M3 quantisation of A and B (amax -> device scale -> cast), then
-  the GEMM, at 8192^3, against the oracle pipeline.
+  the GEMM, then the per-tensor quantisation of the product from the maximum the GEMM's epilogue found, at 8192^3,
+  against the oracle pipeline.
 Bit-exact bar throughout."""
 import numpy as np
 import pytest
@@ -144,8 +145,17 @@ def test_emulated_fp8_gemm_pipeline_8192(hip, bname, variant, fused):
     hip.quantize_per_tensor_(A, Aq, fmt, rm, 448.0)
     hip.quantize_per_tensor_(B, Bq, fmt, rm, 448.0)
     C = torch.zeros(M, N, device=DEV)
-    hip.gemm_(C, Aq, Bq, 1.0, False, False, variant)
+    word = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.gemm_(C, Aq, Bq, 1.0, False, False, variant, amax=word)   # the epilogue folds max |C| into `word`
+    # ... so the per-tensor quantisation of the product (quantize_module_output, reference qutils.py:607-609) is the
+    # cast alone; it must equal amax pass + cast
+    Cq, Cq2 = torch.empty_like(C), torch.empty_like(C)
+    hip.cast_scaled_(C, Cq, fmt, rm, word, 448.0)
+    ws = torch.empty(257, dtype=torch.int32, device=DEV)
+    hip.quantize_per_tensor_(C, Cq2, fmt, rm, 448.0, amax_ws=ws)
     torch.cuda.synchronize()
+    assert int(word.item()) == int(ws[0].item()) == int(np.float32(C.abs().max().item()).view(np.uint32))
+    assert torch.equal(Cq.view(torch.int32), Cq2.view(torch.int32)), "output cast from the epilogue maximum differs"
     Ah, Bh = A.cpu().numpy(), B.cpu().numpy()
     Aqh = orc.cast(Ah, "E4M3_RNE", scale=orc.scale_from_amax(orc.amax(Ah), 448.0))
     Bqh = orc.cast(Bh, "E4M3_RNE", scale=orc.scale_from_amax(orc.amax(Bh), 448.0))
@@ -156,4 +166,7 @@ def test_emulated_fp8_gemm_pipeline_8192(hip, bname, variant, fused):
     want = orc.gemm(Aqh[i], np.ascontiguousarray(Bqh[:, j]), 1.0, fused=fused)
     assert_bits_equal(C[ti][:, tj].cpu().numpy(), want, bname + " pipeline 8192^3 sampled grid")
     rows = [1, M - 2]
-    assert_bits_equal(C[rows].cpu().numpy(), orc.gemm(Aqh[rows], Bqh, 1.0, fused=fused), bname + " pipeline rows")
+    crows = orc.gemm(Aqh[rows], Bqh, 1.0, fused=fused)
+    assert_bits_equal(C[rows].cpu().numpy(), crows, bname + " pipeline rows")
+    s_out = orc.scale_from_amax(np.array([int(word.item())], np.uint32).view(np.float32)[0], 448.0)
+    assert_bits_equal(Cq[rows].cpu().numpy(), orc.cast(crows, "E4M3_RNE", scale=s_out), bname + " pipeline: quantised product rows")

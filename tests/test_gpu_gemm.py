@@ -238,3 +238,100 @@ def test_chain_kernel_forms_vs_oracle(hip, M, N, K, nseg, nb, at, bt):
         Acat = np.concatenate([A[b, s].T if at else A[b, s] for s in range(nseg)], axis=1)   # [M, nseg * K]
         Bcat = np.concatenate([B[b, s].T if bt else B[b, s] for s in range(nseg)], axis=0)   # [nseg * K, N]
         assert_bits_equal(got[b], orc.gemm(Acat, Bcat, 1.0, False, False, fused=True), "chain %s batch %d" % ((M, N, K, nseg, at, bt), b))
+
+
+# ---- the epilogue's output maximum (fpemu_gemm_f32_amax; reference qutils.py:586-609 quantises the product next) ----
+AMAX_SHAPES = [(1, 1, 1), (129, 127, 17), (256, 384, 512), (1000, 8, 2048), (96, 160, 1664), (33, 31, 129),
+               (384, 384, 256), (16, 16, 4096), (2950, 2944, 70), (2944, 2944, 64), (2048, 2048, 64)]
+
+
+@pytest.mark.parametrize("bname,variant,fused", VARIANTS)
+@pytest.mark.parametrize("shape", AMAX_SHAPES)
+def test_gemm_amax_epilogue(hip, bname, variant, fused, shape):
+    """Every kernel behind fpemu_gemm_f32 (tile sizes by problem size, whole and ragged tiles): the _amax form writes the
+    same C bit for bit and its word is bits(max |C|) of the FINAL C (alpha and the accumulate included); the word
+    accumulates over calls; a NaN wins."""
+    M, N, K = shape
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    A = _t(rng.standard_normal((M, K)).astype(np.float32))
+    B = _t(rng.standard_normal((K, N)).astype(np.float32))
+    C0 = _t((rng.standard_normal((M, N)) * 4).astype(np.float32))
+    plain, withmax = C0.clone(), C0.clone()
+    word = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.gemm_(plain, A, B, 0.75, False, False, variant)
+    hip.gemm_(withmax, A, B, 0.75, False, False, variant, amax=word)
+    assert torch.equal(plain.view(torch.int32), withmax.view(torch.int32)), "the matrix changed"
+    want = int(np.float32(plain.abs().max().item()).view(np.uint32))
+    assert int(word.item()) == want, (hex(int(word.item())), hex(want))
+    # a second product into the same word: the maximum of both
+    small = torch.zeros(M, N, device=DEV)
+    hip.gemm_(small, A * 1e-3, B, 1.0, False, False, variant, amax=word)
+    assert int(word.item()) == want
+    big = torch.zeros(M, N, device=DEV)
+    hip.gemm_(big, A * 64.0, B, 1.0, False, False, variant, amax=word)
+    assert int(word.item()) == int(np.float32(max(big.abs().max().item(), plain.abs().max().item())).view(np.uint32))
+    # NaN: above every number, as torch.max
+    A2 = A.clone()
+    A2[M // 2, K // 2] = float("nan")
+    word.zero_()
+    hip.gemm_(torch.zeros(M, N, device=DEV), A2, B, 1.0, False, False, variant, amax=word)
+    assert (int(word.item()) & 0x7FFFFFFF) > 0x7F800000
+
+
+def test_gemm_amax_errors(hip):
+    C = torch.zeros(4, 4, device=DEV)
+    A = torch.zeros(4, 3, device=DEV)
+    B = torch.zeros(3, 4, device=DEV)
+    with pytest.raises(ValueError):
+        hip.gemm_(C, A, B, amax=torch.zeros(1, device=DEV))                     # float word
+    with pytest.raises(ValueError):
+        hip.gemm_(C, A, B, amax=torch.zeros(1, dtype=torch.int32))              # host word
+    L = hip.lib()
+    assert L.fpemu_gemm_f32_amax(C.data_ptr(), A.data_ptr(), B.data_ptr(), 4, 4, 3, 3, 4, 4, 1.0, 0, 0, 1, None, None) == -1
+
+
+@pytest.mark.parametrize("acc", ["fma", "separate"])
+def test_simple_matmul_leaves_its_maximum_for_quantize_tensor(hip, acc, monkeypatch):
+    """mpemu.cmodel.simple with collect_output_amax(True): quantize_tensor of the product (per-tensor max) takes the
+    epilogue's word -- one cast, no amax pass -- and gives the bits of the ordinary path and of the oracle."""
+    from mpemu import qutils
+    from mpemu.cmodel import simple
+
+    rng = np.random.default_rng(21)
+    a = (rng.standard_normal((300, 260)) * 2).astype(np.float32)
+    b = rng.standard_normal((260, 200)).astype(np.float32)
+    cfg = qutils.TensorQuantConfig("e4m3", "rne", "per-tensor")
+    simple.set_accumulation(acc)
+    prev = simple.collect_output_amax(True)
+    calls = []
+    real = hip.cast_scaled_
+    monkeypatch.setattr(hip, "cast_scaled_", lambda *a_, **k: (calls.append(1), real(*a_, **k))[1])
+    try:
+        y = simple.mm(_t(a), _t(b))
+        q = qutils.quantize_tensor(y, cfg, None, inplace=False)
+        assert calls == [1], "the known maximum was not used"
+        prod = orc.gemm(a, b, fused=acc == "fma")
+        want = orc.cast(prod, "E4M3_RNE", scale=orc.scale_from_amax(orc.amax(prod), 448.0))
+        assert_bits_equal(q.cpu().numpy(), want, "quantised product")
+        # a tensor that is NOT the one the op produced never takes the word
+        y2 = simple.mm(_t(a), _t(b))
+        other = y2.clone()
+        qutils.quantize_tensor(other, cfg, None, inplace=False)
+        assert calls == [1] and hip._known is None
+        # ... nor one changed in place since
+        y3 = simple.mm(_t(a), _t(b))
+        y3.mul_(2.0)
+        q3 = qutils.quantize_tensor(y3, cfg, None, inplace=False)
+        assert calls == [1]
+        assert_bits_equal(q3.cpu().numpy(), orc.cast(prod * 2, "E4M3_RNE", scale=orc.scale_from_amax(orc.amax(prod * 2), 448.0)),
+                          "changed in place")
+        # a stack of matrices times a matrix: one word for all slices, in place this time
+        yb = simple.matmul(torch.stack([_t(a), _t(a * 3)]), _t(b))
+        qutils.quantize_tensor(yb, cfg, None, inplace=True)
+        assert calls == [1, 1]
+        pb = np.stack([prod, orc.gemm(a * 3, b, fused=acc == "fma")])
+        assert_bits_equal(yb.cpu().numpy(), orc.cast(pb, "E4M3_RNE", scale=orc.scale_from_amax(orc.amax(pb), 448.0)), "stack")
+    finally:
+        simple.collect_output_amax(prev)
+        simple.set_accumulation("fma")
+        hip.forget_amax()
