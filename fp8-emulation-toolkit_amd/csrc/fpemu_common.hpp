@@ -159,8 +159,8 @@ template <int DT> __device__ __forceinline__ uint32_t absmax_word(uint32_t m, ui
   }
 }
 
-inline unsigned elem_size(int dtype) { return dtype == FPEMU_F32 ? 4u : 2u; }
-inline unsigned vec_elems(int dtype) { return dtype == FPEMU_F32 ? 4u : 8u; }
+inline unsigned elem_size(int dtype) { return dtype == FPEMU_F32 ? 4u : dtype == FPEMU_F64 ? 8u : 2u; }
+inline unsigned vec_elems(int dtype) { return dtype == FPEMU_F32 ? 4u : dtype == FPEMU_F64 ? 2u : 8u; }
 
 }  // namespace fpemu
 

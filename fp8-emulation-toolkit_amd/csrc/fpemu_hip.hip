@@ -360,6 +360,41 @@ __global__ __launch_bounds__(BLOCK) void cast_kernel(const void *in_, void *out_
                                     gridDim.x);
 }
 
+// float64 storage (FPEMU_F64): the reference's GPU dispatcher takes double tensors (hip/fpemu_kernels.hip:1070) and
+// its kernels compute `float inval = in[gid] * scale` with both operands double -- ONE rounding of the double
+// product to fp32 -- then the fp32 algorithm, and widen `h.f * scale_reciprocal` back (hip:429-431, 472).  The same
+// here: p = (float)(x * (double)scale); cast_one(p, 1, rcp); widen.  One 16-byte vector (two elements) per lane, one
+// shot; element i draws the noise of element elem_base + i of the fp32 layout, so a tensor gives the same random
+// bits whichever of the two widths stores it.  Twice the bytes per element of the fp32 cast, the same stream.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <int FMT, int RM>
+__device__ __forceinline__ double cast_one_f64(double x, double dscale, float rcp, uint64_t seed, uint64_t offset,
+                                               uint64_t idx) {
+  uint32_t rnd = 0u;
+  if constexpr (RM == STOCHASTIC) rnd = rand_bits_elem<FMT, 4>(seed, offset, idx);
+  return (double)cast_one<FMT, RM>((float)(x * dscale), 1.0f, rcp, rnd);
+}
+
+template <int FMT, int RM>
+__global__ __launch_bounds__(kBlock) void cast64_kernel(const double *in, double *out, uint64_t nvec, uint64_t n,
+                                                        float scale, float rcp, uint64_t seed, uint64_t offset,
+                                                        uint64_t elem_base) {
+  const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const double dscale = (double)scale;
+  if (gid < nvec) {
+    const f64x2 v = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(in) + gid);
+    f64x2 o;
+    o[0] = cast_one_f64<FMT, RM>(v[0], dscale, rcp, seed, offset, elem_base + 2u * gid);
+    o[1] = cast_one_f64<FMT, RM>(v[1], dscale, rcp, seed, offset, elem_base + 2u * gid + 1u);
+    __builtin_nontemporal_store(o, reinterpret_cast<f64x2 *>(out) + gid);
+  }
+  // the odd last element, or a whole buffer that is not 16-byte aligned (launched with nvec == 0)
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t e = nvec * 2u + gid; e < n; e += stride)
+    out[e] = cast_one_f64<FMT, RM>(in[e], dscale, rcp, seed, offset, elem_base + e);
+}
+
 // Multi-tensor cast: one launch for up to kMultiTensors buffers of the same storage type and mode (the
 // emulators re-quantise every master parameter after the optimizer step -- emulator_base.py
 // update_fp16_master_params: 161 launches per ResNet-50 step, most of them a few microseconds of
@@ -650,6 +685,29 @@ template <int DT> cast_multi_scaled_fn pick_cast_multi_scaled(int fmt, int rm) {
   return nullptr;  // BF16 / FP16 take no scale
 }
 
+typedef void (*cast64_fn)(const double *, double *, uint64_t, uint64_t, float, float, uint64_t, uint64_t, uint64_t);
+
+cast64_fn pick_cast64(int fmt, int rm) {
+#define FPEMU_CASE(F, R) \
+  if (fmt == F && rm == R) return cast64_kernel<F, R>;
+  FPEMU_CASE(E5M2, RTZ) FPEMU_CASE(E5M2, RNE) FPEMU_CASE(E5M2, STOCHASTIC) FPEMU_CASE(E5M2, RNAZ)
+  FPEMU_CASE(E5M2, RNTZ) FPEMU_CASE(E5M2, RPINF) FPEMU_CASE(E5M2, RNINF)
+  FPEMU_CASE(E5M2_DAZ, RNE) FPEMU_CASE(E5M2_DAZ, STOCHASTIC) FPEMU_CASE(E5M2_DAZ, RNAZ)
+  FPEMU_CASE(E5M2_DAZ, RNTZ)
+  FPEMU_CASE(E4M3, RTZ) FPEMU_CASE(E4M3, RNE) FPEMU_CASE(E4M3, STOCHASTIC)
+  FPEMU_CASE(E3M4, RTZ) FPEMU_CASE(E3M4, RNE) FPEMU_CASE(E3M4, STOCHASTIC)
+  FPEMU_CASE(BF16, RTZ) FPEMU_CASE(BF16, RNE) FPEMU_CASE(BF16, STOCHASTIC)
+  FPEMU_CASE(FP16, RNE) FPEMU_CASE(FP16, STOCHASTIC)
+  FPEMU_CASE(FP16_DAZ, RNE)
+  FPEMU_CASE(E4M3_IEEE, RNE) FPEMU_CASE(E4M3_IEEE, STOCHASTIC)
+  FPEMU_CASE(FP4, RNE)
+#undef FPEMU_CASE
+  return nullptr;
+}
+
+// float64 storage: plain casts with a host-side scale only (see cast64_kernel)
+int launch_cast64(const void *in, void *out, uint64_t n, int fmt, int rmode, const CastParams &prm, void *stream);
+
 cast_fn pick_cast_dt(int dtype, int fmt, int rm, bool wide = false) {
   switch (dtype) {
     case FPEMU_F32: return pick_cast<FPEMU_F32>(fmt, rm, wide);
@@ -669,6 +727,7 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
                 const CastParams &prm, void *stream) {
   if (n == 0) return FPEMU_OK;
   if (in == nullptr || out == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast: null buffer");
+  if (dtype == FPEMU_F64) return launch_cast64(in, out, n, fmt, rmode, prm, stream);
   if (dtype < FPEMU_F32 || dtype > FPEMU_BF16) return fail(FPEMU_EINVAL, "fpemu_cast: bad dtype id");
   const bool wide = prm.npart != 0u;
   cast_fn fn = pick_cast_dt(dtype, fmt, rmode, wide);
@@ -692,6 +751,27 @@ int launch_cast(const void *in, void *out, uint64_t n, int dtype, int fmt, int r
 
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kCastBlock), 0, (hipStream_t)stream, in, out, nsb,
                      n, prm.scale, prm.rcp, prm.amax_bits, prm.npart, prm.clamp, prm.rest);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  return FPEMU_OK;
+}
+
+int launch_cast64(const void *in, void *out, uint64_t n, int fmt, int rmode, const CastParams &prm, void *stream) {
+  if (prm.amax_bits != nullptr || prm.npart != 0u)
+    return fail(FPEMU_EINVAL, "float64 storage: only fpemu_cast / fpemu_forward (a scale given by the host) take it");
+  const cast64_fn fn = pick_cast64(fmt, rmode);
+  if (fn == nullptr) return fail(FPEMU_EINVAL, "fpemu_cast: format / rounding-mode pair not defined");
+  if (((uintptr_t)in % 8u) || ((uintptr_t)out % 8u))
+    return fail(FPEMU_EALIGN, "fpemu_cast: buffer not aligned to its element size");
+  const bool vec_ok = (((uintptr_t)in | (uintptr_t)out) % 16u) == 0;
+  const uint64_t nvec = vec_ok ? n / 2u : 0;
+  const uint64_t tail = n - nvec * 2u;
+  uint64_t blocks = (nvec + kBlock - 1) / kBlock;
+  const uint64_t tail_blocks = (tail + kBlock - 1) / kBlock;
+  if (blocks < tail_blocks) blocks = tail_blocks;
+  if (blocks > 0x7FFFFFFFull) return fail(FPEMU_EINVAL, "fpemu_cast: float64 buffer too large for one launch");
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, (const double *)in, (double *)out,
+                     nvec, n, prm.scale, prm.rcp, prm.rest.seed, prm.rest.offset, prm.rest.elem_base);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
   return FPEMU_OK;

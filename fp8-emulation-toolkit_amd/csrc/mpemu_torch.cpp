@@ -25,8 +25,9 @@ int dtype_id(const at::Tensor &t) {
     case at::kFloat: return FPEMU_F32;
     case at::kHalf: return FPEMU_F16;
     case at::kBFloat16: return FPEMU_BF16;
+    case at::kDouble: return FPEMU_F64;   // plain casts only (fpemu_cast); the library refuses it elsewhere
     default:
-      TORCH_CHECK_TYPE(false, "fpemu: unsupported tensor dtype ", t.scalar_type(), " (float32, float16, bfloat16 only)");
+      TORCH_CHECK_TYPE(false, "fpemu: unsupported tensor dtype ", t.scalar_type(), " (float32, float64, float16, bfloat16 only)");
   }
 }
 

@@ -17,8 +17,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libfpemu_hip.so")
 
-F32, F16, BF16 = 0, 1, 2
-_DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+F32, F16, BF16, F64 = 0, 1, 2, 3
+# float64 storage: plain casts with a host-side scale (fpemu_cast / fpemu_forward); the library refuses it elsewhere
+_DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16, torch.float64: F64}
 
 # format ids / flt_max of include/fpemu_hip.h
 FMT_E5M2, FMT_E4M3, FMT_E3M4, FMT_BF16, FMT_FP16, FMT_E5M2_DAZ, FMT_FP16_DAZ = range(7)
@@ -163,7 +164,7 @@ def _dtype_id(t):
     try:
         return _DTYPES[t.dtype]
     except KeyError:
-        raise TypeError("fpemu: unsupported tensor dtype %s (float32, float16, bfloat16 only)" % t.dtype)
+        raise TypeError("fpemu: unsupported tensor dtype %s (float32, float64, float16, bfloat16 only)" % t.dtype)
 
 
 def _require_device(t, what="input"):

@@ -8,7 +8,8 @@ estimator.
 
 Differences from the reference, all deliberate (DESIGN.md "Boundary"):
   * an unknown mode string raises ValueError (the reference silently returns zeros / the input);
-  * bfloat16 tensors are accepted (the reference GPU path rejects them), float64 is not;
+  * bfloat16 tensors are accepted (the reference GPU path rejects them); float64 tensors take plain casts
+    (block norm excepted), as on the reference's GPU path;
   * backward returns one gradient per forward input (the reference returns 5 for 6 inputs);
   * importing this module does not call torch.manual_seed (the reference does, fpemu.py:19);
   * stochastic modes draw from a counter-based Philox stream: see manual_seed() below.

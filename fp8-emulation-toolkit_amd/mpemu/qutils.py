@@ -437,7 +437,8 @@ def _plan(qtconfig):
 def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
     """Single entry point for quantising a tensor (qutils.py:264-345)."""
     plan = getattr(qtconfig, "_plan", None) or _plan(qtconfig)
-    if plan[0] and _amax_group is None and tensor.is_cuda and not tensor.is_sparse:
+    f64 = tensor.dtype == torch.float64   # plain casts only on the device; scales are computed as the reference does
+    if plan[0] and _amax_group is None and tensor.is_cuda and not tensor.is_sparse and not (f64 and plan[0] == 1):
         if plan[0] == 1 and _hip._known is not None:
             word = _hip.take_amax(tensor)   # left by the c-model op that produced this very tensor
             if word is not None:
@@ -456,7 +457,10 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
     mode = qtconfig.dtype.upper()
     if qtconfig.scheme is not None:
         mode += "_" + qtconfig.scheme.upper()
-    on_device = _device_tensor(tensor) and "INT" not in mode
+    # float64 tensors (the reference's GPU dispatcher takes them, hip/fpemu_kernels.hip:1070): the statistic and the
+    # scale are computed by torch in double and handed over as a float, exactly as the reference's Python does
+    # (qutils.py:276-287); the device-side scale paths are float32 / 16-bit only
+    on_device = _device_tensor(tensor) and "INT" not in mode and not f64
 
     if qtconfig.scaling is True:
         if qtconfig.scaling_method == "max" and on_device:

@@ -29,8 +29,14 @@ extern "C" {
 
 #define FPEMU_ABI_VERSION 10
 
-/* Storage dtype of in/out buffers. */
-enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2 };
+/* Storage dtype of in/out buffers.  FPEMU_F64 is served by fpemu_cast / fpemu_forward (plain casts, no block norm)
+ * only -- the reference's GPU dispatcher takes double tensors (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * hip/fpemu_kernels.hip:1070), its CPU path does not (data_ptr<float>, cpp/fpemu_impl.cpp:1879).  Semantics, as its
+ * kernels compute (hip/fpemu_kernels.hip:429-431, 472): p = (float)(x * (double)scale), one rounding; the fp32
+ * algorithm on p with scale 1; out = (double)(q * rcp).  Noise is indexed by element exactly as for fp32 storage.
+ * Every other entry point answers FPEMU_EINVAL for it (a per-tensor scale of a double tensor is computed by the
+ * caller in double, as the reference's Python does, and handed to fpemu_cast). */
+enum { FPEMU_F32 = 0, FPEMU_F16 = 1, FPEMU_BF16 = 2, FPEMU_F64 = 3 };
 
 /* Emulated target format.  One id per reference kernel:
  *   E5M2      E5M2_Kernel        cpp/fpemu_impl.cpp:765   (scalar routine :691-763 is canonical)

@@ -199,7 +199,9 @@ def test_forward_signature_and_errors(hip):
     with pytest.raises(RuntimeError):
         hip.forward(x.cpu(), "E4M3_RNE", x.numel(), False, 1.0, False, 1)
     with pytest.raises(TypeError):
-        hip.forward(x.double(), "E4M3_RNE", x.numel(), False, 1.0, False, 1)
+        hip.forward(x.to(torch.int32), "E4M3_RNE", x.numel(), False, 1.0, False, 1)
+    with pytest.raises(ValueError):   # float64 storage: plain casts only, no block norm
+        hip.forward(x.double(), "E4M3_RNE", x.numel(), False, 1.0, True, 8)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -603,3 +605,88 @@ def test_quantize_per_tensor_multi_argument_errors(hip):
         hip.quantize_per_tensor_multi_(t, *hip.parse_mode("E4M3_RNE"), 448.0, ws=torch.empty(5, dtype=torch.int32, device=DEV))
     with pytest.raises(ValueError):  # mixed dtypes
         hip.quantize_per_tensor_multi_([t[0], t[1].half()], *hip.parse_mode("E4M3_RNE"), 448.0)
+
+
+def _assert_f64_equal(got, want, what):
+    """Bit-for-bit equality of two float64 arrays; positions where both sides are NaN count as equal."""
+    g = np.ascontiguousarray(got, np.float64).ravel()
+    w = np.ascontiguousarray(want, np.float64).ravel()
+    bad = np.nonzero((g != w) & ~(np.isnan(g.view(np.float64)) & np.isnan(w.view(np.float64))))[0]
+    assert bad.size == 0, "%s: %d / %d differ; first at %s got %s want %s" % (
+        what, bad.size, g.size, bad[:6].tolist(), [hex(v) for v in g[bad[:6]]], [hex(v) for v in w[bad[:6]]])
+
+
+def _oracle_f64(x64, mode, scale=1.0, seed=0, offset=0, elem_base=0):
+    """float64 storage as the reference's GPU kernels treat it (hip/fpemu_kernels.hip:429-431, 472): ONE rounding of
+    the double product x * scale to fp32, the fp32 algorithm on it, the fp32 product with the reciprocal, widened."""
+    s32 = np.float32(scale)
+    with np.errstate(over="ignore", invalid="ignore"):
+        p = (np.asarray(x64, np.float64) * np.float64(s32)).astype(np.float32)
+    q = orc.cast(p, mode, scale=1.0, seed=seed, offset=offset, elem_base=elem_base)
+    rcp = np.float32(1.0 / np.float64(s32))
+    return (q * rcp).astype(np.float64)
+
+
+@pytest.mark.parametrize("mode", ["E5M2_RNE", "E5M2_RTZ", "E5M2_STOCHASTIC", "E4M3_RNE", "E4M3_STOCHASTIC", "E3M4_RNE",
+                                  "BFLOAT16_RNE", "BFLOAT16_STOCHASTIC", "FLOAT16_RNE", "E5M2_DAZ_RNE", "E4M3_IEEE_RNE",
+                                  "FP4_NEAREST"])
+def test_float64_storage_vs_oracle(hip, mode):
+    """double tensors, which the reference's GPU dispatcher accepts (hip/fpemu_kernels.hip:1070; its CPU path is
+    fp32-only, so parity is otherwise unpinned): whole vectors, an odd tail, an unaligned view, a scale, in place, and
+    values that need the double -> float rounding (beyond fp32's precision and range)."""
+    rng = np.random.default_rng(64)
+    n = 100003
+    x = rng.standard_normal(n) * np.exp(rng.standard_normal(n) * 4)
+    x[:8] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e300, -1e-300, 1.0 + 2.0 ** -30]
+    x[8:16] = [448.0, 57344.0, 464.0 - 2.0 ** -40, 1.0625 + 2.0 ** -45, 2.0 ** -150, 3.0e38, 3.5e38, -2.0 ** -9]
+    fmt, rm = hip.parse_mode(mode)
+    t = torch.from_numpy(x).to(DEV)
+    for scale in (1.0, 3.7):
+        if scale != 1.0 and mode.split("_")[0] in ("BFLOAT16", "FLOAT16"):
+            continue
+        y = torch.empty_like(t)
+        hip.cast_(t, y, fmt, rm, scale=scale, seed=9, offset=4)
+        want = _oracle_f64(x, mode, scale, seed=9, offset=4)
+        _assert_f64_equal(y.cpu().numpy(), want, "%s f64 scale %g" % (mode, scale))
+    # an unaligned (8- but not 16-byte) view with elem_base, in place
+    buf = torch.empty(n + 1, dtype=torch.float64, device=DEV)
+    buf[1:].copy_(t)
+    view = buf[1:]
+    assert view.data_ptr() % 16 == 8
+    hip.cast_(view, view, fmt, rm, scale=1.0, seed=9, offset=4, elem_base=1 << 20)
+    _assert_f64_equal(view.cpu().numpy(),
+                      _oracle_f64(x, mode, 1.0, seed=9, offset=4, elem_base=1 << 20),
+                      mode + " f64 unaligned in place")
+
+
+def test_float64_through_the_operator_and_quantize_tensor(hip):
+    """FPEmuOp.apply / forward() / quantize_tensor with double tensors: plain casts run in the float64 kernel; per-tensor
+    scaling computes max and scale with torch in double and hands the scale over as a float, as the reference's Python
+    does (qutils.py:282-287) -- no device-side scale for this width."""
+    from mpemu import qutils
+    from mpemu.pytquant import fpemu_cuda
+
+    rng = np.random.default_rng(65)
+    x = rng.standard_normal((37, 53)) * 5
+    t = torch.from_numpy(x).to(DEV)
+    y = fpemu_cuda.FPEmuOp.apply(t, "E4M3_RNE", False, 2.0)
+    assert y.dtype == torch.float64
+    _assert_f64_equal(y.cpu().numpy(), _oracle_f64(x, "E4M3_RNE", 2.0), "FPEmuOp f64")
+    out = hip.forward(t, "E5M2_RNE", t.numel(), False, 1.0, False, 1)[0]
+    _assert_f64_equal(out.cpu().numpy(), _oracle_f64(x, "E5M2_RNE"), "forward f64")
+    cfg = qutils.TensorQuantConfig("e4m3", "rne", "per-tensor")
+    q = qutils.quantize_tensor(t, cfg, None, inplace=False)
+    scale = 448.0 / np.abs(x).max()               # double arithmetic, then a C float at the boundary
+    scale = 6.55e4 if scale > 3.275e4 else scale
+    _assert_f64_equal(q.cpu().numpy(), _oracle_f64(x, "E4M3_RNE", np.float32(scale)),
+                      "quantize_tensor f64 per-tensor")
+    qc = qutils.quantize_tensor(t, qutils.TensorQuantConfig("e5m2", "rne", "per-channel"), None, inplace=False)
+    for r in (0, 36):
+        s = 57344.0 / np.abs(x[r]).max()
+        s = 6.55e4 if s > 3.275e4 else s
+        _assert_f64_equal(qc[r].cpu().numpy(), _oracle_f64(x[r], "E5M2_RNE", np.float32(s)),
+                          "quantize_tensor f64 per-channel row %d" % r)
+    with pytest.raises(ValueError):
+        hip.amax_(t, torch.zeros(1, dtype=torch.int32, device=DEV))
+    with pytest.raises(ValueError):
+        hip.quantize_per_tensor_(t, torch.empty_like(t), *hip.parse_mode("E4M3_RNE"), 448.0)
