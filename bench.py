@@ -246,6 +246,11 @@ def main():
     # and W is the driver's to choose.
     for _ in range(SPINUP_STEPS):
         step()
+    # the timed region's two events exist before it starts (torch creates an event at its first record: a
+    # hipEventCreate inside the region otherwise, tools/wall_overhead.py)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    ev1.record()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -254,7 +259,6 @@ def main():
     # run on (torch's current stream, which the binding passes to the C ABI): the wall clock gives `value`, the events
     # give the dominant kernel's average launch duration over the same launches (`roofline`).  (An event after every
     # launch, as round 1 had it, puts a marker packet between consecutive kernels: ~1 % of a 0.31 ms launch.)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
@@ -580,7 +584,25 @@ def main():
                                 "frac_of_bare_pipe": round(tf / cc[bare], 4) if bare in cc else None,
                                 "timing": "10 untimed launches, then two HIP events around 10; min from 5 more, one event each",
                                 "verified": verified[name]}
-            del ga, gb_, gc
+            # per-tensor quantisation of the 256 MiB product (quantize_module_output, reference qutils.py:607-609): amax pass
+            # + cast, against the cast alone from the maximum the GEMM's epilogue found (fpemu_gemm_f32_amax)
+            wq = torch.zeros(1, dtype=torch.int32, device=dev)
+            qf, qr = hip.parse_mode("E4M3_RNE")
+            gc.zero_()
+            hip.gemm_(gc, ga, gb_, 1.0, False, False, 1, amax=wq)
+            gq, gq2 = torch.empty_like(gc), torch.empty_like(gc)
+            ws_q = torch.empty(257, dtype=torch.int32, device=dev)
+            q_two = time_batch(lambda: hip.quantize_per_tensor_(gc, gq2, qf, qr, 448.0, amax_ws=ws_q), launches=20, warm=3)
+            q_one = time_batch(lambda: hip.cast_scaled_(gc, gq, qf, qr, wq, 448.0), launches=20, warm=3)
+            verified["gemm_output_quantise"] = bool(torch.equal(gq.view(torch.int32), gq2.view(torch.int32))) and same(
+                gq[si][:, sj].contiguous(),
+                orc.cast(orc.gemm(ha, hbm, 1.0, fused=True), "E4M3_RNE", scale=orc.scale_from_amax(
+                    np.array([int(wq.item())], np.uint32).view(np.float32)[0], 448.0)))
+            extras["gemm_output_quantise"] = {
+                "amax_pass_plus_cast_ms": round(q_two, 5), "cast_from_epilogue_amax_ms": round(q_one, 5),
+                "GB/s": round(8 * gc.numel() / (q_one * 1e-3) / 1e9, 1), "tensor_MiB": gc.numel() * 4 >> 20,
+                "verified": verified["gemm_output_quantise"]}
+            del ga, gb_, gc, gq, gq2
 
             # cmodel convolution: ResNet-50's 3x3, 64 -> 64 channels, 56 x 56, batch 32
             try:

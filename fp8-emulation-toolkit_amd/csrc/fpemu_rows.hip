@@ -290,7 +290,7 @@ template <int DT, int NV, int BLOCK = kBlock, int RPL = 1> rows_reg_fn pick_rows
 #ifndef FPEMU_ROWS_PAIR16
 #define FPEMU_ROWS_PAIR16 1   // tuning: 16-bit storage, one vector per lane, lane group within a wave: two rows per lane
 #endif
-// rocprofv3 kernel durations, bf16 E4M3_RNE block norm over 64 Mi elements (tools/rows_trace.sh), two rows per lane
+// rocprofv3 kernel durations, bf16 E4M3_RNE block norm over 64 Mi elements (tools/gpu.sh rows-trace), two rows per lane
 // vs one: blocks of 8 (one lane per row) 44.9 vs 42.7 us, 32: 44.3 vs 44.3, 128: 44.9 vs 45.8, 512: 45.0 vs 48.1 --
 // the second vector in flight pays once the row's maximum crosses lanes, so groups of 8 lanes and more take it.
 constexpr int rows_per_lane(int dtype, uint32_t per_lane, uint32_t lg) {

@@ -3,7 +3,7 @@
 // fpemu_device.hpp; variants differ only in how bytes move.  Interleaved rounds in ONE process
 // (cdna_hip_programming.md rule 24); prints median and min GB/s per variant.
 //
-//   make -C fp8-emulation-toolkit_amd/csrc && tools/build_sweep.sh   (links libfpemu_hip.so; also builds
+//   make -C fp8-emulation-toolkit_amd/csrc && tools/gpu.sh build-sweep   (links libfpemu_hip.so; also builds
 //   tools/sweep_pl with gfx950 kernarg preload on the sweep's own kernels)
 //   ./tools/sweep [elements=268435456] [rounds=15]
 #include <hip/hip_runtime.h>
