@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -1460,9 +1461,9 @@ template <int TW> mfma_fn pick_mfma_tw(bool chain, bool full, bool a_kcont, bool
                : (full ? pick_mfma<false, true, TW>(a_kcont, b_kcont) : pick_mfma<false, false, TW>(a_kcont, b_kcont));
 }
 
-int launch_gemm(const char *who, float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
-                int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans, int variant,
-                bool chain, int64_t batch, Batch bt, void *stream) {
+int launch_gemm_(const char *who, float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                 int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans, int variant,
+                 bool chain, int64_t batch, Batch bt, void *stream, bool split_ok) {
   char msg[160];
   auto fail = [&](int code, const char *what) {
     snprintf(msg, sizeof(msg), "%s: %s", who, what);
@@ -1483,13 +1484,40 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   const bool a_kcont = !a_trans, b_kcont = b_trans != 0;
   a.pad = -0.0f;
   b.pad = 0.0f;
-  a.vec = aligned16(A) && (lda % 4 == 0) && (bt.sa % 4 == 0) && ((a_kcont ? K : M) % 4 == 0);
-  b.vec = aligned16(B) && (ldb % 4 == 0) && (bt.sb % 4 == 0) && ((b_kcont ? K : N) % 4 == 0);
+  // base pointer, leading dimension and batch stride allow 16-byte loads; the extent along the contiguous axis decides
+  const bool a_vec_base = aligned16(A) && (lda % 4 == 0) && (bt.sa % 4 == 0);
+  const bool b_vec_base = aligned16(B) && (ldb % 4 == 0) && (bt.sb % 4 == 0);
+  a.vec = a_vec_base && ((a_kcont ? K : M) % 4 == 0);
+  b.vec = b_vec_base && ((b_kcont ? K : N) % 4 == 0);
   const int c_vec = aligned16(C) && (ldc % 4 == 0) && (bt.sc % 4 == 0) && (N % 4 == 0);
   if (bt.nseg < 1) return fail(FPEMU_EINVAL, "k_segments must be >= 1");
   if (bt.nseg > 1 && ((bt.ka % 4) || (bt.kb % 4))) a.vec = b.vec = 0;
   const int tb = fpemu_gemm_tile_edge_(M, N, batch, variant);   // 16 / 32: the small-tile chain kernels
   const bool tiny = tb == 16, small = tb <= 32;
+  // Ragged M or N on the large-tile kernels: one ragged edge used to put EVERY tile on the bounds-checked loads
+  // (4100 x 4090 x 4096: 0.56 of the MFMA peak against 0.88 whole).  Outputs are independent chains, so the problem is
+  // cut along M and N instead: the interior of whole tiles (unchecked 16-byte loads), then the right strip and the
+  // bottom strip as problems of their own (their tile size chosen for their own shape).  Same chains, same bits.
+  // Plain GEMMs only (the chain / batched / segmented forms come from the convolution, which pads to whole tiles).
+  static const bool no_split = getenv("FPEMU_GEMM_NOSPLIT") != nullptr;   // tuning aid (tools/gemm_bench.py)
+  if (variant == 1 && !no_split && !chain && batch == 1 && bt.nseg == 1 && !small && split_ok && K > 0 && (M % tb || N % tb) && M >= tb && N >= tb &&
+      a_vec_base && b_vec_base && K % (variant == 1 ? MBK : BK) == 0) {
+    const int64_t Mi = (M / tb) * tb, Ni = (N / tb) * tb;
+    int rc = launch_gemm_(who, C, A, B, Mi, Ni, K, lda, ldb, ldc, alpha, a_trans, b_trans, variant, chain, batch, bt, stream,
+                          /*split_ok=*/false);
+    if (rc != FPEMU_OK) return rc;
+    if (Ni < N) {   // right strip: all M rows, columns Ni..N
+      rc = launch_gemm_(who, C + Ni, A, b_kcont ? B + Ni * ldb : B + Ni, M, N - Ni, K, lda, ldb, ldc, alpha, a_trans,
+                        b_trans, variant, chain, batch, bt, stream, false);
+      if (rc != FPEMU_OK) return rc;
+    }
+    if (Mi < M) {   // bottom strip: rows Mi..M, columns 0..Ni
+      rc = launch_gemm_(who, C + Mi * ldc, a_kcont ? A + Mi * lda : A + Mi, B, M - Mi, Ni, K, lda, ldb, ldc, alpha, a_trans,
+                        b_trans, variant, chain, batch, bt, stream, false);
+      if (rc != FPEMU_OK) return rc;
+    }
+    return FPEMU_OK;
+  }
   const int tiles_m = (int)((M + tb - 1) / tb), tiles_n = (int)((N + tb - 1) / tb);
   const int64_t nwg = (int64_t)tiles_m * tiles_n;
   if (nwg > 0x7FFFFFFF) return fail(FPEMU_EINVAL, "too many tiles");
@@ -1530,6 +1558,13 @@ int launch_gemm(const char *who, float *C, const float *A, const float *B, int64
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FPEMU_OK : fail((int)e, hipGetErrorString(e));
+}
+
+int launch_gemm(const char *who, float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
+                int64_t lda, int64_t ldb, int64_t ldc, float alpha, int a_trans, int b_trans, int variant,
+                bool chain, int64_t batch, Batch bt, void *stream) {
+  return launch_gemm_(who, C, A, B, M, N, K, lda, ldb, ldc, alpha, a_trans, b_trans, variant, chain, batch, bt, stream,
+                      /*split_ok=*/true);
 }
 
 }  // namespace

@@ -596,30 +596,36 @@ GEMM_SEPARATE, GEMM_FMA = 0, 1
 # A c-model op whose epilogue folded max |output| into a device word leaves (output, word) here; the per-tensor
 # quantisation of that very tensor right afterwards (quantize_module_output, reference qutils.py:607-609) then skips
 # its amax pass.  ONE slot, holding the tensor itself: while it is held its address cannot be handed to another
-# tensor, and any in-place change since bumps _version -- a stale entry can never match.
-_known = None
+# tensor, and any in-place change since bumps _version -- a stale entry can never match.  Per host thread (hooks may
+# run on several): a producer on one thread never clobbers or feeds another thread's consumer.
+class _Known(threading.local):
+    slot = None
+
+
+_known_tls = _Known()
 
 
 def note_amax(t, word):
     """`word` (int32[1] on t's device) holds bits(max |t|) in stream order; t is as the producer left it."""
-    global _known
-    _known = (t, t.data_ptr(), t.numel(), t._version, word)
+    _known_tls.slot = (t, t.data_ptr(), t.numel(), t._version, word)
+
+
+def has_known_amax():
+    return _known_tls.slot is not None
 
 
 def take_amax(t):
-    """The amax word of t if the last c-model op produced exactly this tensor (same storage, size, dtype, version),
-    else None.  Either way the slot is emptied."""
-    global _known
-    k, _known = _known, None
+    """The amax word of t if the last c-model op on this thread produced exactly this tensor (same storage, size,
+    dtype, version), else None.  Either way the slot is emptied."""
+    k, _known_tls.slot = _known_tls.slot, None
     if (k is not None and k[1] == t.data_ptr() and k[2] == t.numel() and k[3] == t._version
-            and k[0].dtype == t.dtype and t.is_contiguous()):
+            and k[0].dtype == t.dtype and k[0].device == t.device and t.is_contiguous()):
         return k[4]
     return None
 
 
 def forget_amax():
-    global _known
-    _known = None
+    _known_tls.slot = None
 
 
 def gemm_(C, A, B, alpha=1.0, a_trans=False, b_trans=False, variant=GEMM_FMA, amax=None):

@@ -439,7 +439,7 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
     plan = getattr(qtconfig, "_plan", None) or _plan(qtconfig)
     f64 = tensor.dtype == torch.float64   # plain casts only on the device; scales are computed as the reference does
     if plan[0] and _amax_group is None and tensor.is_cuda and not tensor.is_sparse and not (f64 and plan[0] == 1):
-        if plan[0] == 1 and _hip._known is not None:
+        if plan[0] == 1 and _hip.has_known_amax():
             word = _hip.take_amax(tensor)   # left by the c-model op that produced this very tensor
             if word is not None:
                 return _KnownAmaxCast.apply(tensor, bool(inplace), plan[2], plan[3], plan[4], word)

@@ -311,7 +311,7 @@ def test_hooked_conv_output_quantised_from_the_epilogue_maximum(hip, monkeypatch
     try:
         with torch.no_grad():
             y_fast = conv(x).clone()
-        assert calls == [1] and hip._known is None and simple._collect is False
+        assert calls == [1] and not hip.has_known_amax() and simple._collect is False
         conv.weight.data.copy_(w0)
         monkeypatch.setattr(simple, "collect_output_amax", lambda on: False)   # collection off: the ordinary path
         with torch.no_grad():

@@ -317,7 +317,7 @@ def test_simple_matmul_leaves_its_maximum_for_quantize_tensor(hip, acc, monkeypa
         y2 = simple.mm(_t(a), _t(b))
         other = y2.clone()
         qutils.quantize_tensor(other, cfg, None, inplace=False)
-        assert calls == [1] and hip._known is None
+        assert calls == [1] and not hip.has_known_amax()
         # ... nor one changed in place since
         y3 = simple.mm(_t(a), _t(b))
         y3.mul_(2.0)
@@ -335,3 +335,25 @@ def test_simple_matmul_leaves_its_maximum_for_quantize_tensor(hip, acc, monkeypa
         simple.collect_output_amax(prev)
         simple.set_accumulation("fma")
         hip.forget_amax()
+
+
+@pytest.mark.parametrize("bname,variant,fused", VARIANTS)
+@pytest.mark.parametrize("shape", [(4100, 4092, 64), (1100, 1028, 64), (4096, 4092, 32), (4100, 4096, 96)])
+@pytest.mark.parametrize("at,bt", [(False, False), (True, True), (False, True)])
+def test_gemm_ragged_edges_interior_and_strips(hip, bname, variant, fused, shape, at, bt):
+    """Ragged M and / or N with aligned operands and whole k tiles: the launch is cut into the interior of whole tiles
+    (unchecked loads) plus a right and a bottom strip.  Whole matrix against the oracle, accumulate and alpha included,
+    and the epilogue maximum over all three launches."""
+    M, N, K = shape
+    rng = np.random.default_rng(M + N + K + at + 2 * bt)
+    A = rng.standard_normal((K, M) if at else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if bt else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    C = _t(C0)
+    word = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.gemm_(C, _t(A), _t(B), 0.5, at, bt, variant, amax=word)
+    prod = orc.gemm(A, B, 1.0, at, bt, fused=fused)
+    want = C0 + (np.float32(0.5) * prod + np.float32(0.0) * C0)   # impl.cpp:226-231, element by element
+    got = C.cpu().numpy()
+    assert_bits_equal(got, want, "%s %s at=%d bt=%d" % (bname, shape, at, bt))
+    assert int(word.item()) == int(np.abs(want).max().view(np.uint32))
