@@ -98,3 +98,30 @@ def test_graphed_forward_of_a_hooked_model():
         assert torch.equal(want.view(torch.int32), got.view(torch.int32)), seed
     with pytest.raises(ValueError):
         fwd(torch.randn(10, 96, device=DEV))
+
+
+def test_memoised_quantisation_stays_out_of_graph_capture():
+    """A result produced under stream capture holds nothing until the graph is replayed: such calls neither read nor feed
+    the one-entry memo of quantize_tensor, and eager calls after the capture compute their own result."""
+    from mpemu import qutils
+
+    cfg = qutils.TensorQuantConfig("e4m3", "rne", "per-tensor")
+    x = torch.randn(4096, device="cuda:0") * 3
+    eager = qutils.quantize_tensor(x, cfg, None, inplace=False).clone()
+    qutils._memo.slot = None
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        qutils.quantize_tensor(x, cfg, None, inplace=False)      # warm: workspace allocation outside the capture
+        qutils._memo.slot = None
+        with torch.cuda.graph(g, stream=side):
+            captured = qutils.quantize_tensor(x, cfg, None, inplace=False)
+    torch.cuda.current_stream().wait_stream(side)
+    assert qutils._memo.slot is None, "a captured call fed the memo"
+    after = qutils.quantize_tensor(x, cfg, None, inplace=False)
+    assert after is not captured and torch.equal(after, eager)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, eager)

@@ -236,3 +236,60 @@ def test_nan_and_negative_infinite_scales_run_as_in_the_reference():
     cfg = qutils.TensorQuantConfig("e4m3", "rne", "fine-grained", group_size=2)
     q = qutils.quantize_tensor(w, cfg, None, inplace=False)
     assert torch.isnan(q[3]).any() and torch.isfinite(q[4]).all()
+
+
+def test_shared_input_is_quantised_once_and_never_stale():
+    """Consecutive out-of-place deterministic quantisations of one unchanged tensor with one configuration (the q / k / v
+    projections' shared input, reference qutils.py:528-534) return the first result; anything that could change the
+    answer drops the entry: another configuration, an in-place change of the input or of the result, an in-place
+    quantisation in the same storage, a stochastic mode."""
+    from mpemu import qutils
+    from mpemu.pytquant.hip import _binding as hip
+
+    cfg = qutils.TensorQuantConfig("e4m3", "rne", "per-tensor")
+    cfg2 = qutils.TensorQuantConfig("e5m2", "rne", "per-tensor")
+    wcfg = qutils.TensorQuantConfig("e4m3", "rne", "per-tensor")
+    plain = qutils.TensorQuantConfig("e5m2", "rne")
+    sr = qutils.TensorQuantConfig("e5m2", "stochastic")
+    rng = np.random.default_rng(3)
+    xh = (rng.standard_normal((64, 300)) * 3).astype(np.float32)
+    x = torch.from_numpy(xh).to(DEV)
+    want = lambda a, mode, fm: orc.cast(a, mode, scale=orc.scale_from_amax(orc.amax(a), fm))
+    q1 = qutils.quantize_tensor(x, cfg, None, inplace=False)
+    w = torch.randn(32, 32, device=DEV)
+    qutils.quantize_tensor(w, wcfg, None, inplace=True)           # the next module's weight, in place: unrelated storage
+    q2 = qutils.quantize_tensor(x, cfg, None, inplace=False)
+    assert q2 is q1, "the shared input was quantised again"
+    assert_bits_equal(q1.cpu().numpy(), want(xh, "E4M3_RNE", 448.0), "memoised result")
+    q3 = qutils.quantize_tensor(x, cfg2, None, inplace=False)     # another configuration
+    assert q3 is not q1
+    assert_bits_equal(q3.cpu().numpy(), want(xh, "E5M2_RNE", 57344.0), "other configuration")
+    q4 = qutils.quantize_tensor(x, cfg2, None, inplace=False)
+    assert q4 is q3
+    x.mul_(2.0)                                                   # the input changed in place
+    q5 = qutils.quantize_tensor(x, cfg2, None, inplace=False)
+    assert q5 is not q3
+    assert_bits_equal(q5.cpu().numpy(), want(xh * 2, "E5M2_RNE", 57344.0), "after an in-place change of the input")
+    q5.add_(1.0)                                                  # a consumer wrote into the result
+    q6 = qutils.quantize_tensor(x, cfg2, None, inplace=False)
+    assert q6 is not q5
+    assert_bits_equal(q6.cpu().numpy(), want(xh * 2, "E5M2_RNE", 57344.0), "after an in-place change of the result")
+    qutils.quantize_tensor(x, cfg, None, inplace=True)            # in place, same storage (raw write, no _version move)
+    xq = want(xh * 2, "E4M3_RNE", 448.0)
+    q7 = qutils.quantize_tensor(x, cfg2, None, inplace=False)
+    assert q7 is not q6
+    assert_bits_equal(q7.cpu().numpy(), want(xq, "E5M2_RNE", 57344.0), "after an in-place quantisation of the input")
+    p1 = qutils.quantize_tensor(x, plain, None, inplace=False)    # the unscaled cast memoises too
+    assert qutils.quantize_tensor(x, plain, None, inplace=False) is p1
+    hip.manual_seed(5)
+    s1 = qutils.quantize_tensor(x, sr, None, inplace=False)       # stochastic: every call draws its own noise
+    s2 = qutils.quantize_tensor(x, sr, None, inplace=False)
+    assert s2 is not s1 and not torch.equal(s1, s2)
+    xr = x.clone().requires_grad_(True)                           # autograd state is part of the key
+    g1 = qutils.quantize_tensor(xr, cfg, None, inplace=False)
+    with torch.no_grad():
+        g2 = qutils.quantize_tensor(xr, cfg, None, inplace=False)
+    assert g1.requires_grad and not g2.requires_grad
+    g3 = qutils.quantize_tensor(xr, cfg, None, inplace=False)
+    (g1.sum() + g3.sum()).backward()                              # straight-through, twice
+    assert torch.equal(xr.grad, torch.full_like(xr, 2.0))
