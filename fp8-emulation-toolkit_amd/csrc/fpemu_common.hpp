@@ -114,6 +114,38 @@ struct ElemNoise {
   __device__ __forceinline__ uint32_t pair(unsigned e) const { return one(e) | (one(e + 1u) << 16); }
 };
 
+// The same noise for a WHOLE 16-byte vector whose first element has an index that is a multiple of V: its V elements are
+// one slot of one lane of the layout, so their noise bytes are consecutive bytes of ONE Philox call -- one draw per
+// vector instead of one per element (ElemNoise cannot share them: the compiler does not see that base + e stays in the
+// slot).  Stochastic rows / block norm, fp32: 3.6-3.9 -> the deterministic kernels' rate (tools/rows_bench.py).
+template <int FMT, unsigned V>
+struct VecNoise {
+  static constexpr unsigned NB = noise_bytes<FMT>();
+  static constexpr unsigned W = V * NB / 4u;   // words of the call that cover the vector
+  static_assert(V * NB <= 16u && (V * NB) % 4u == 0u, "a vector's noise lies inside one Philox call");
+  uint32_t w[W];
+  __device__ __forceinline__ VecNoise(uint64_t seed, uint64_t call, uint64_t base) {
+    constexpr uint64_t SB = (uint64_t)V * 64u * 4u;
+    const uint64_t sb = base / SB;
+    const unsigned r = (unsigned)(base % SB);
+    const unsigned slot = r / (V * 64u);
+    const unsigned lane = (r / V) % 64u;
+    const unsigned pos = slot * V * NB;          // byte of the lane's draw where the vector's noise starts
+    const Philox4 p = philox4x32_10(seed, ((sb * 64u + lane) << 2) | (uint64_t)(pos / 16u), call);
+#pragma unroll
+    for (unsigned i = 0; i < W; i++) w[i] = philox_word(p, (pos % 16u) / 4u + i);
+  }
+  __device__ __forceinline__ uint32_t one(unsigned e) const {
+    const unsigned pos = e * NB;                 // compile-time after unrolling
+    const uint32_t v = w[pos / 4u] >> ((pos % 4u) * 8u);
+    return NB == 2 ? (v & 0xFFFFu) : (v & 0xFFu);
+  }
+  __device__ __forceinline__ uint32_t pair(unsigned e) const {   // e even; one noise byte per element
+    if constexpr (NB == 1) return __builtin_amdgcn_perm(0u, w[e / 4u], (e % 4u) == 0u ? 0x0C010C00u : 0x0C030C02u);
+    else return one(e) | (one(e + 1u) << 16);
+  }
+};
+
 // One step of an ASCENDING max butterfly: m <- max(m, m of the partner group of OFF lanes).  Before the step m is
 // uniform over aligned groups of OFF lanes (steps 1, 2, ... OFF/2 have run), so any lane of the partner group will do:
 // OFF 1 / 2 are quad permutes, OFF 4 / 8 the half-row / row mirrors (lane i <-> 7-i / 15-i lands in the partner

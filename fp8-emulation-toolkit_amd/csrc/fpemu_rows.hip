@@ -113,8 +113,15 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(const void *in_, void *out
   const float rcp = scale_reciprocal(scale);
   const uint64_t roff = offset + row;
 
+  const bool vec_noise = (col_base % V) == 0;   // uniform: every vector is one slot of one lane of the noise layout
   for (uint64_t i = t; i < nvec; i += TS) {
-    const u32x4 o = cast_vector<FMT, RM, DT>(vin[i], scale, rcp, ElemNoise<FMT, V>{seed, roff, col_base + i * V});
+    u32x4 o;
+    if constexpr (SR) {
+      if (vec_noise) o = cast_vector<FMT, RM, DT>(vin[i], scale, rcp, VecNoise<FMT, V>(seed, roff, col_base + i * V));
+      else o = cast_vector<FMT, RM, DT>(vin[i], scale, rcp, ElemNoise<FMT, V>{seed, roff, col_base + i * V});
+    } else {
+      o = cast_vector<FMT, RM, DT>(vin[i], scale, rcp, NoNoise{});
+    }
     vout[i] = o;
   }
 #pragma clang loop vectorize(disable) interleave(disable)
@@ -255,6 +262,8 @@ __global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *
     }
   }
 
+  constexpr bool SR = (RM == STOCHASTIC);   // col_base % V == 0 here (the host sends other segments to rows_kernel): every
+                                            // vector is one slot of one lane of the noise layout, one draw per vector
 #pragma unroll
   for (int q = 0; q < R; q++) {
     const float rcp = scale_reciprocal(scale[q]);
@@ -263,7 +272,12 @@ __global__ __launch_bounds__(BLOCK) void rows_reg_kernel(const void *in_, void *
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       const uint32_t i = (uint32_t)k * G + t;
-      const u32x4 o = cast_vector<FMT, RM, DT>(v[q][k], scale[q], rcp, ElemNoise<FMT, V>{seed, roff, col_base + (uint64_t)i * V});
+      u32x4 o;
+      if constexpr (SR) {
+        o = cast_vector<FMT, RM, DT>(v[q][k], scale[q], rcp, VecNoise<FMT, V>(seed, roff, col_base + (uint64_t)i * V));
+      } else {
+        o = cast_vector<FMT, RM, DT>(v[q][k], scale[q], rcp, NoNoise{});
+      }
       if (live[q] && i < nv) store_stream(&vout[i], o);
     }
   }
@@ -552,7 +566,10 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
     return FPEMU_OK;
   }
   // register-resident path: aligned rows of at most kBlock * kRegVecs vectors
-  if ((((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % ve) == 0 && cols / ve <= (uint64_t)kBlock * (unsigned)reg_vecs(dtype)) {
+  // (a row segment whose first column is not a multiple of the vector's elements straddles the noise layout's slots:
+  // rows_kernel below keeps the per-element draw for it)
+  const bool noise_aligned = rmode != STOCHASTIC || (col_base % ve) == 0;
+  if (noise_aligned && (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % ve) == 0 && cols / ve <= (uint64_t)kBlock * (unsigned)reg_vecs(dtype)) {
     const uint32_t nv = (uint32_t)(cols / ve);
     // lane group: the smallest power of two covering the row's vectors, up to a wave; longer rows keep the
     // wave (<= 4 vectors per lane) or take the whole block; a lone row is spread over the block
@@ -581,7 +598,7 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
     return FPEMU_OK;
   }
   // longer aligned rows, up to kBigBlock * kBigRegVecs vectors: the 512- / 1024-thread register-resident forms
-  if ((((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % ve) == 0 &&
+  if (noise_aligned && (((uintptr_t)in | (uintptr_t)out) % 16u) == 0 && (cols % ve) == 0 &&
       cols / ve <= (uint64_t)kBigBlock * (unsigned)big_reg_vecs(dtype)) {
     const uint32_t nv = (uint32_t)(cols / ve);
     // Measured on MI355X (tools/rows_quick.py, 64 Mi elements, TB/s at 8 | 4 B/element; 1024- vs 512-thread groups):
