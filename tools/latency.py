@@ -8,6 +8,7 @@ from mpemu.pytquant.hip import _binding as hip
 from mpemu.pytquant import fpemu_cuda
 
 dev = "cuda:0"
+qutils._MEMO_ON = False   # every call here repeats the last one: time the call, not the memo of its result
 cfg_t = qutils.TensorQuantConfig("e4m3", "rne", "per-tensor")
 cfg_c = qutils.TensorQuantConfig("e4m3", "rne", "per-channel")
 cfg_n = qutils.TensorQuantConfig("e5m2", "stochastic")
