@@ -105,3 +105,17 @@ def test_argument_errors_without_gpu():
     assert L.fpemu_amax(16, 0, 0, 16, None) == 0
     assert L.fpemu_cast_scaled(16, 16, 4, 0, 1, 1, None, 448.0, 1, 0, 0, 0, None) == -1
     assert L.fpemu_quantize_per_tensor(16, 16, 4, 0, 1, 1, 448.0, 1, None, 0, 0, None) == -1
+
+
+def test_header_is_plain_c_and_cxx():
+    """include/fpemu_hip.h is the drop-in boundary: it must compile as C99 and as C++ on its own (no torch, no HIP
+    headers), so a cgo / JNI / pybind / ctypes-generating consumer can include it as is."""
+    import shutil
+    import subprocess
+
+    hdr = os.path.join(ROOT, "include", "fpemu_hip.h")
+    for cc, args in (("gcc", ["-std=c99", "-pedantic", "-x", "c"]), ("g++", ["-std=c++11", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(cc + " not installed")
+        r = subprocess.run([cc, "-Wall", "-Werror", "-fsyntax-only"] + args + [hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
