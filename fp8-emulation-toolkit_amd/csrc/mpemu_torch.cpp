@@ -99,6 +99,23 @@ at::Tensor quantize_per_tensor_impl(const at::Tensor &input, bool inplace, int64
   return inplace ? input : dst;
 }
 
+// quantize_tensor's per-channel / fine-grained "max" branches (reference qutils.py:289-337: a Python loop of per-row
+// casts that never goes through autograd): one launch of the rows kernel over the [rows, numel / rows] view.
+// offset: first of the `rows` consecutive call offsets a loop of per-row casts would draw (stochastic modes).
+at::Tensor quantize_rows(const at::Tensor &input, bool inplace, int64_t fmt, int64_t rmode, double flt_max, int64_t rows,
+                         bool clamp, uint64_t seed, uint64_t offset) {
+  TORCH_CHECK(input.is_cuda(), "fpemu: input must live on a ROCm device (got ", input.device(), "); this build has no CPU path");
+  TORCH_CHECK(rows > 0 && input.numel() % rows == 0, "fpemu: ", input.numel(), " elements do not split into ", rows, " rows");
+  at::Tensor src = input.contiguous();
+  at::Tensor dst = inplace ? src : at::empty_like(src);
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(src.device());
+  const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(src.get_device());
+  check(fpemu_quantize_rows(src.data_ptr(), dst.data_ptr(), (uint64_t)rows, (uint64_t)(src.numel() / rows), dtype_id(src),
+                            (int)fmt, (int)rmode, (float)flt_max, clamp ? 1 : 0, seed, offset, (void *)stream.stream()));
+  if (inplace && !src.is_same(input)) input.copy_(src);
+  return inplace ? input : dst;
+}
+
 // Straight-through estimator (reference pytquant/cpp/fpemu.py:68-71): the gradient passes unchanged.
 struct CastSTE : public torch::autograd::Function<CastSTE> {
   static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &input, bool inplace, int64_t fmt,
@@ -152,4 +169,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("seed"), py::arg("offset"));
   m.def("quantize_per_tensor", &quantize_per_tensor, py::arg("input"), py::arg("inplace"), py::arg("fmt"), py::arg("rmode"),
         py::arg("flt_max"), py::arg("clamp"), py::arg("seed"), py::arg("offset"), py::arg("workspace") = py::none());
+  m.def("quantize_rows", &quantize_rows, py::arg("input"), py::arg("inplace"), py::arg("fmt"), py::arg("rmode"),
+        py::arg("flt_max"), py::arg("rows"), py::arg("clamp"), py::arg("seed"), py::arg("offset"));
 }

@@ -419,7 +419,8 @@ def _mean_scale(sample, qtconfig, threshold, use_mode):
 def _plan(qtconfig):
     """(kind, mode, fmt, rmode, flt_max) of a configuration, computed once per configuration state (the hooks
     call quantize_tensor tens to hundreds of times per step with the same few configurations):
-    kind 1 = per-tensor max scaling, 2 = plain cast, 0 = everything else (the general code below)."""
+    kind 1 = per-tensor max scaling, 2 = plain cast, 3 = per-channel max scaling, 0 = everything else (the general
+    code below)."""
     qtconfig.check_validity(qtconfig.dtype, qtconfig.scheme)
     mode = qtconfig.dtype.upper()
     if qtconfig.scheme is not None:
@@ -429,7 +430,9 @@ def _plan(qtconfig):
         fmt, rmode = _hip.parse_mode(mode)
         if qtconfig.scaling is True:
             kind = 1 if (qtconfig.scaling_method == "max" and fmt not in _NO_SCALE_FMTS) else 0
-        elif not qtconfig.per_channel and not qtconfig.fine_grained:
+        elif qtconfig.per_channel is True:
+            kind = 3 if (qtconfig.scaling_method == "max" and fmt not in _NO_SCALE_FMTS) else 0
+        elif not qtconfig.fine_grained:
             kind = 2
     plan = (kind, mode, fmt, rmode, qtconfig.get_flt_max())
     qtconfig._plan = plan
@@ -487,7 +490,18 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
     if inplace and _memo.slot is not None:
         _memo_invalidate(tensor)
     f64 = tensor.dtype == torch.float64   # plain casts only on the device; scales are computed as the reference does
-    if plan[0] and _amax_group is None and tensor.is_cuda and not tensor.is_sparse and not (f64 and plan[0] == 1):
+    if plan[0] == 3:
+        # per-channel "max": one native call (checks, allocation, the rows kernel); the reference's loop over dim 0
+        # never goes through autograd for the pieces (qutils.py:289-311), so there is no node to build
+        ext = _hip.ext()
+        rows = tensor.shape[0] if tensor.dim() >= 1 else 0
+        if (ext is not None and rows > 0 and _amax_group is None and tensor.is_cuda and not tensor.is_sparse and not f64
+                and not _hip.tracing() and (rows >= 64 or tensor.numel() // rows <= (1 << 16))):
+            q = ext.quantize_rows(tensor.detach(), bool(inplace), plan[2], plan[3], plan[4], rows, True,
+                                  _hip.get_rng_state()[0],
+                                  _hip.take_offsets(rows) if plan[3] == _hip.STOCHASTIC else 0)
+            return tensor if inplace else q
+    elif plan[0] and _amax_group is None and tensor.is_cuda and not tensor.is_sparse and not (f64 and plan[0] == 1):
         if plan[0] == 1 and _hip.has_known_amax():
             word = _hip.take_amax(tensor)   # left by the c-model op that produced this very tensor
             if word is not None:
