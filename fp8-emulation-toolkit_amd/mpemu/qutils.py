@@ -448,14 +448,30 @@ class _Memo(threading.local):
     amax passes and casts.  The entry holds both tensors (an address cannot be reused while it lives) and is dropped on
     any mismatch: another tensor, an in-place change of the input (its _version moved) or of the result (a consumer
     wrote into it), another configuration, another autograd state.  Stochastic modes never enter (every call draws its
-    own noise), nor do calls under stream capture.  Cost: the last input / result pair stays alive until the next
-    out-of-place quantisation on the thread.  Measured: BERT-base 8 x 128 with E4M3 PTQ hooks 3.93 -> 3.85 ms (24 of its
+    own noise), nor do calls under stream capture.  Only calls made inside `shared_input_memo()` take part -- the
+    forward-pre hook's quantisation of a module's INPUTS: activations are real autograd tensors, whose in-place changes
+    move their _version, whereas weights are reached through `.data` aliases (a fresh version counter per access: a
+    `weight.data.copy_(...)` between two calls would go unseen).  Cost: the last input / result pair stays alive until
+    the next such quantisation on the thread.  Measured: BERT-base 8 x 128 with E4M3 PTQ hooks 3.93 -> 3.85 ms (24 of its
     148 casts per forward are repeats).  MPEMU_NO_MEMO=1 switches it off."""
     slot = None
+    depth = 0     # > 0: inside shared_input_memo()
 
 
 _memo = _Memo()
 _MEMO_ON = os.environ.get("MPEMU_NO_MEMO", "0") in ("", "0")
+
+
+class shared_input_memo(object):
+    """Context: out-of-place deterministic quantize_tensor calls on this thread may reuse / feed the one-entry memo."""
+
+    def __enter__(self):
+        _memo.depth += 1
+        return self
+
+    def __exit__(self, *a):
+        _memo.depth -= 1
+        return False
 
 
 def _memo_lookup(tensor, plan):
@@ -511,7 +527,7 @@ def quantize_tensor(tensor, qtconfig, qtparams, inplace=False):
             # the two cases every hook call is: one native call does checks, allocation, launch(es) and the
             # straight-through autograd node (csrc/mpemu_torch.cpp)
             # (never under stream capture: a captured call's result holds nothing until the graph is replayed)
-            memo = (_MEMO_ON and not inplace and plan[3] != _hip.STOCHASTIC
+            memo = (_memo.depth > 0 and _MEMO_ON and not inplace and plan[3] != _hip.STOCHASTIC
                     and not torch.cuda.is_current_stream_capturing())
             if memo:
                 hit = _memo_lookup(tensor, plan)
@@ -734,7 +750,8 @@ def quantize_module_weights_and_inputs(self, input):
     if _active(qc.wt_qconfig):
         self.weight.data = quantize_tensor(self.weight.data, qc.wt_qconfig, self.qparams.wt_qparams, inplace=True)
     if _active(qc.iact_qconfig):
-        input = tuple(quantize_tensor(t, qc.iact_qconfig, None, inplace=False) for t in input)
+        with shared_input_memo():   # modules that share an input: the repeat of the last quantisation is its result
+            input = tuple(quantize_tensor(t, qc.iact_qconfig, None, inplace=False) for t in input)
     return input
 
 

@@ -113,14 +113,15 @@ def test_memoised_quantisation_stays_out_of_graph_capture():
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
+    with torch.cuda.stream(side), qutils.shared_input_memo():
         qutils.quantize_tensor(x, cfg, None, inplace=False)      # warm: workspace allocation outside the capture
         qutils._memo.slot = None
         with torch.cuda.graph(g, stream=side):
             captured = qutils.quantize_tensor(x, cfg, None, inplace=False)
     torch.cuda.current_stream().wait_stream(side)
     assert qutils._memo.slot is None, "a captured call fed the memo"
-    after = qutils.quantize_tensor(x, cfg, None, inplace=False)
+    with qutils.shared_input_memo():
+        after = qutils.quantize_tensor(x, cfg, None, inplace=False)
     assert after is not captured and torch.equal(after, eager)
     g.replay()
     torch.cuda.synchronize()

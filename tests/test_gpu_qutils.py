@@ -255,6 +255,21 @@ def test_shared_input_is_quantised_once_and_never_stale():
     xh = (rng.standard_normal((64, 300)) * 3).astype(np.float32)
     x = torch.from_numpy(xh).to(DEV)
     want = lambda a, mode, fm: orc.cast(a, mode, scale=orc.scale_from_amax(orc.amax(a), fm))
+    # outside shared_input_memo() nothing is memoised: weights are reached through `.data` aliases, whose in-place
+    # changes no version counter shows (quantize_weights_of_a_module called twice must give q(q(w)))
+    lin = torch.nn.Linear(300, 64).to(DEV)
+    lin.weight.data.copy_(x)
+    qutils.quantize_weights_of_a_module(lin, cfg)
+    once = lin.weight.data.clone()
+    qutils.quantize_weights_of_a_module(lin, cfg)
+    assert_bits_equal(once.cpu().numpy(), want(xh, "E4M3_RNE", 448.0), "q(w)")
+    assert_bits_equal(lin.weight.data.cpu().numpy(), want(want(xh, "E4M3_RNE", 448.0), "E4M3_RNE", 448.0), "q(q(w))")
+    assert qutils.quantize_tensor(x, cfg, None, inplace=False) is not qutils.quantize_tensor(x, cfg, None, inplace=False)
+    with qutils.shared_input_memo():
+        _memoised_calls(qutils, hip, x, xh, cfg, cfg2, wcfg, plain, sr, want)
+
+
+def _memoised_calls(qutils, hip, x, xh, cfg, cfg2, wcfg, plain, sr, want):
     q1 = qutils.quantize_tensor(x, cfg, None, inplace=False)
     w = torch.randn(32, 32, device=DEV)
     qutils.quantize_tensor(w, wcfg, None, inplace=True)           # the next module's weight, in place: unrelated storage
