@@ -201,10 +201,27 @@ class ShardedCaster(object):
         self.ops.cast_(shard, out, fmt, rmode, scale=scale, seed=seed, offset=offset, elem_base=elem_base)
         return out
 
-    def amax_words(self, shards):
-        """One int32 word per shard (bit pattern of max|x|), reduced over the group in ONE call."""
+    def _scratch_word(self, like):
+        """One reusable amax word per (device, stream) of this caster: calls on one stream are ordered, so the word of
+        the previous call has been consumed by its cast before this call's zeroing runs; no allocation per call."""
+        if not like.is_cuda or torch.cuda.is_current_stream_capturing():
+            return None
+        key = (like.device, torch.cuda.current_stream(like.device).cuda_stream)
+        cache = self.__dict__.setdefault("_words", {})
+        w = cache.get(key)
+        if w is None:
+            w = cache[key] = torch.zeros(1, dtype=torch.int32, device=like.device)
+        return w
+
+    def amax_words(self, shards, out=None):
+        """One int32 word per shard (bit pattern of max|x|), reduced over the group in ONE call.  out: optional int32
+        buffer of len(shards) words on the shards' device to use instead of a fresh one."""
         dev = shards[0].device
-        words = torch.zeros(len(shards), dtype=torch.int32, device=dev)
+        if out is not None:
+            words = out[:len(shards)]
+            words.zero_()
+        else:
+            words = torch.zeros(len(shards), dtype=torch.int32, device=dev)
         for i, s in enumerate(shards):
             self.ops.amax_(s, words[i:i + 1])
         if self._world() > 1:
@@ -282,7 +299,7 @@ class ShardedCaster(object):
         tensor: local amax -> all-reduce(MAX) of one word -> device-side scale -> local cast."""
         fmt, rmode = self.ops.parse_mode(mode)
         if amax_word is None:
-            amax_word = self.amax_words([shard])
+            amax_word = self.amax_words([shard], out=self._scratch_word(shard))
         out = shard if inplace else torch.empty_like(shard)
         self.ops.cast_scaled_(shard, out, fmt, rmode, amax_word, flt_max, clamp=clamp, seed=seed,
                               offset=offset, elem_base=elem_base)
