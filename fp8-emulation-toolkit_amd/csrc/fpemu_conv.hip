@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/fpemu_hip.h"
 
@@ -272,8 +273,20 @@ struct Phase {
   int pitch;       // floats per row of the phase's gathered matrix and phase plane (Hh * Wh rounded up to whole tiles)
 };
 
+// All phases of a call that have taps and pixels, with where their packed weights and gathered matrices live: ONE
+// pack launch and ONE gather launch (blockIdx.y / .z = phase) instead of one of each per phase -- thirteen launches per
+// 3 x 3 stride-2 backward-data call became seven.
+struct PhaseSet {
+  Phase ph[16];
+  int64_t woff[16];   // floats from the start of the packed-weight area
+  int64_t goff[16];   // floats from the start of the chunk's gathered area
+  int count;
+};
+
 // Wph[c][(ob, aj, ai, o2)] = w[ob*KB + o2][c][kj][ki], kj = kj0 + (nj - 1 - aj) * st (descending), ki = ki0 + ai * st
-__global__ __launch_bounds__(NT) void pack_w_bp_phase(const float *__restrict__ w, float *__restrict__ Wm, Geo g, Phase ph) {
+__global__ __launch_bounds__(NT) void pack_w_bp_phase(const float *__restrict__ w, float *__restrict__ Wm_, Geo g, PhaseSet ps) {
+  const Phase ph = ps.ph[blockIdx.y];
+  float *Wm = Wm_ + ps.woff[blockIdx.y];
   const int64_t krs = g.K * ph.nj * ph.ni, total = g.C * krs;
   const int st = (int)g.stride;
   for (int64_t i = gtid(); i < total; i += gstride()) {
@@ -291,10 +304,13 @@ __global__ __launch_bounds__(NT) void pack_w_bp_phase(const float *__restrict__ 
 // colsp[n][(ob, aj, ai, o2)][(yh, xh)] = gout[n][ob*KB + o2][yh + dj][xh + di] (0 outside), rows of ph.pitch floats
 // with a +0 tail.  One gathered row per blockIdx.y, threads along the phase's pixels.
 template <int RB>   // rows per block trip: RB consecutive output channels o2 of one tap (see cols_fp); needs KB % RB == 0
-__global__ __launch_bounds__(NT) void cols_bp_phase(const float *__restrict__ go, float *__restrict__ cols, Geo g, Phase ph,
-                                                    int64_t nrows) {
+__global__ __launch_bounds__(NT) void cols_bp_phase(const float *__restrict__ go, float *__restrict__ cols_, Geo g, PhaseSet ps,
+                                                    int64_t nimg) {
+  const Phase ph = ps.ph[blockIdx.z];   // uniform: scalar loads from the kernel arguments
+  float *cols = cols_ + ps.goff[blockIdx.z];
   const int OH = (int)g.OH, OW = (int)g.OW, st = (int)g.stride, Wh = ph.Wh, HWp = ph.Hh * ph.Wh;
   const int krs = (int)g.K * ph.nj * ph.ni;
+  const int64_t nrows = nimg * krs;
   const int64_t plane = (int64_t)OH * OW;
   for (int64_t row = (int64_t)blockIdx.y * RB; row < nrows; row += (int64_t)gridDim.y * RB) {
     int kk = (int)(row % krs);
@@ -648,8 +664,8 @@ int make_geo(const char *who, Geo &g, int64_t N, int64_t C, int64_t H, int64_t W
 // floats: packed weights (or the packed gradient) + the gathered operand of `chunk` images
 constexpr int64_t kColsCapFloats = (int64_t)1 << 30;  // 4 GiB of gathered operand per chunk at most
 
-// The phases of a strided backward-data convolution (see cols_bp_phase) and what they need per image: a plane per phase
-// plus the largest gathered matrix.  false: not a case for the phase path.
+// The phases of a strided backward-data convolution (see cols_bp_phase) and what they need per image: a plane and a
+// gathered matrix per phase.
 constexpr int kMaxPhaseStride = 4;
 bool bp_by_phase(const Geo &g) { return g.stride > 1 && g.stride <= kMaxPhaseStride && g.C > 4; }
 Phase make_phase(const Geo &g, int py, int px) {
@@ -671,8 +687,7 @@ void bp_phase_floats(const Geo &g, int64_t &planes, int64_t &gathered) {   // pe
       const Phase ph = make_phase(g, py, px);
       if (ph.Hh * ph.Wh == 0 || ph.nj * ph.ni == 0) continue;
       planes += g.C * ph.pitch;
-      const int64_t m = g.K * ph.nj * ph.ni * ph.pitch;
-      gathered = m > gathered ? m : gathered;
+      gathered += g.K * ph.nj * ph.ni * ph.pitch;   // all phases' gathered matrices side by side (one gather launch)
     }
 }
 
@@ -910,36 +925,52 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
     int64_t planes_per_img, gathered_per_img;
     bp_phase_floats(g, planes_per_img, gathered_per_img);
     const int st = (int)stride;
-    Phase phs[kMaxPhaseStride * kMaxPhaseStride];
-    float *wph[kMaxPhaseStride * kMaxPhaseStride];
-    {  // the phases' weights, packed once, side by side in the weight area (their taps partition the filter)
-      float *wp = Wm;
-      for (int p = 0; p < st * st; p++) {
-        phs[p] = make_phase(g, p / st, p % st);
-        wph[p] = nullptr;
-        const int64_t n = C * K * phs[p].nj * phs[p].ni;
-        if (phs[p].Hh * phs[p].Wh == 0 || n == 0) continue;
-        wph[p] = wp;
-        hipLaunchKernelGGL(pack_w_bp_phase, dim3(blocks_for(n)), dim3(NT), 0, s, w, wp, g, phs[p]);
-        CHECK_LAUNCH(who);
-        wp += n;
-      }
+    PhaseSet ps;
+    memset(&ps, 0, sizeof(ps));
+    int slot_of[kMaxPhaseStride * kMaxPhaseStride];   // phase (py * st + px) -> its slot in ps, -1: no tap / no pixel
+    int64_t wtot = 0, gper = 0, wmax = 0, pitch_max = 0, rows_max = 0;
+    for (int p = 0; p < st * st; p++) {
+      const Phase ph = make_phase(g, p / st, p % st);
+      const int64_t n = C * K * ph.nj * ph.ni;
+      slot_of[p] = -1;
+      if (ph.Hh * ph.Wh == 0 || n == 0) continue;
+      const int q = ps.count++;
+      slot_of[p] = q;
+      ps.ph[q] = ph;
+      ps.woff[q] = wtot;    // the phases' weights side by side in the weight area (their taps partition the filter)
+      ps.goff[q] = gper;    // per image here; scaled by the chunk's image count below
+      wtot += n;
+      gper += K * ph.nj * ph.ni * ph.pitch;
+      wmax = n > wmax ? n : wmax;
+      pitch_max = ph.pitch > pitch_max ? ph.pitch : pitch_max;
+      rows_max = K * ph.nj * ph.ni > rows_max ? K * ph.nj * ph.ni : rows_max;
+    }
+    const bool rb4 = g.KB % 4 == 0;   // (then every phase's K * nj * ni is a multiple of 4)
+    if (ps.count > 0) {
+      hipLaunchKernelGGL(pack_w_bp_phase, dim3(blocks_for(wmax), (unsigned)ps.count), dim3(NT), 0, s, w, Wm, g, ps);
+      CHECK_LAUNCH(who);
     }
     for (int64_t n0 = 0; n0 < N; n0 += chunk) {
       const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
       float *plane = cols, *gath = cols + nb * planes_per_img;
+      PhaseSet pc = ps;
+      for (int q = 0; q < ps.count; q++) pc.goff[q] = ps.goff[q] * nb;
+      if (ps.count > 0) {
+        dim3 gg = gather_grid(pitch_max / 4, nb * rows_max / (rb4 ? 4 : 1));
+        gg.z = (unsigned)ps.count;
+        hipLaunchKernelGGL(rb4 ? cols_bp_phase<4> : cols_bp_phase<1>, gg, dim3(NT), 0, s, gout + n0 * K * P, gath, g, pc, nb);
+        CHECK_LAUNCH(who);
+      }
       PhaseTable tb;
       for (int p = 0; p < 16; p++) { tb.plane[p] = nullptr; tb.pitch[p] = 0; tb.Wh[p] = 1; }
       for (int p = 0; p < st * st; p++) {
-        if (wph[p] == nullptr) continue;
-        const Phase &ph = phs[p];
+        const int q = slot_of[p];
+        if (q < 0) continue;
+        const Phase &ph = ps.ph[q];
         const int64_t krs_p = K * ph.nj * ph.ni;
-        const bool rb4 = g.KB % 4 == 0;   // (then krs_p is a multiple of 4)
-        hipLaunchKernelGGL(rb4 ? cols_bp_phase<4> : cols_bp_phase<1>, gather_grid(ph.pitch / 4, nb * krs_p / (rb4 ? 4 : 1)),
-                           dim3(NT), 0, s, gout + n0 * K * P, gath, g, ph, nb * krs_p);
-        CHECK_LAUNCH(who);
-        rc = fpemu_gemm_chain_start_launch_(plane, wph[p], gath, C, ph.pitch, krs_p, krs_p, ph.pitch, ph.pitch, 0, 0,
-                                            variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3, nullptr, 0, nullptr, stream);
+        rc = fpemu_gemm_chain_start_launch_(plane, Wm + ps.woff[q], gath + pc.goff[q], C, ph.pitch, krs_p, krs_p, ph.pitch,
+                                            ph.pitch, 0, 0, variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3, nullptr,
+                                            0, nullptr, stream);
         if (rc != FPEMU_OK) return rc;
         tb.plane[p] = plane; tb.pitch[p] = ph.pitch; tb.Wh[p] = ph.Wh;
         plane += nb * C * ph.pitch;
