@@ -109,3 +109,86 @@ def test_random_rows_and_blocks_vs_oracle(hip):
                 s = orc.scale_from_amax(orc.amax(x[r]), fmax, clamp=(kind == "clamp"))
                 want = orc.cast(x[r], mode, scale=s, seed=31, offset=4000 + r)
                 assert_bits_equal(got[r], want, what + " row %d" % r, nan_payload_ok=True)
+
+
+def test_random_float64_cases_vs_oracle(hip):
+    """float64 storage (round 3): random modes, lengths, misaligned views, scales, shard positions, in place."""
+    rng = np.random.default_rng(64064)
+    for case in range(120):
+        mode = ALL_MODES[int(rng.integers(len(ALL_MODES)))]
+        fmt, rm = hip.parse_mode(mode)
+        n = int(rng.choice([1, 2, 3, 127, 128, 129, 1000, 4097, 65536, 100001]))
+        shift = int(rng.integers(0, 3))
+        scale = 1.0 if mode.split("_")[0] in ("BFLOAT16", "FLOAT16") else float(rng.choice([1.0, 0.37, 3.0, 116.894]))
+        elem_base = int(rng.integers(0, 1 << 20)) * 1024
+        seed, offset = int(rng.integers(1 << 40)), int(rng.integers(1 << 20))
+        inplace = bool(rng.integers(2))
+        x32 = mixed_inputs(n + shift, seed=1000 + case)
+        with np.errstate(over="ignore", invalid="ignore"):
+            x = x32.astype(np.float64) * (1.0 + rng.standard_normal(n + shift) * 2.0 ** -30)   # bits below fp32's
+        t = torch.from_numpy(x).to(DEV)[shift:]
+        o = t if inplace else torch.empty(n + shift, dtype=torch.float64, device=DEV)[shift:]
+        hip.cast_(t, o, fmt, rm, scale=scale, seed=seed, offset=offset, elem_base=elem_base)
+        s32 = np.float32(scale)
+        with np.errstate(over="ignore", invalid="ignore"):
+            p = (x[shift:] * np.float64(s32)).astype(np.float32)
+        q = orc.cast(p, mode, scale=1.0, seed=seed, offset=offset, elem_base=elem_base)
+        want = (q * np.float32(1.0 / np.float64(s32))).astype(np.float64)
+        got = o.cpu().numpy()
+        bad = (got.view(np.uint64) != want.view(np.uint64)) & ~(np.isnan(got) & np.isnan(want))
+        assert not bad.any(), "f64 case %d: %s n=%d shift=%d scale=%r inplace=%s: %d differ" % (
+            case, mode, n, shift, scale, inplace, int(bad.sum()))
+
+
+def test_random_16bit_rows_vs_oracle(hip):
+    """Per-row quantisation of fp16 / bf16 storage, stochastic modes included (one Philox draw per 8-element vector since
+    round 3), over random shapes: the oracle's 16-bit cast of each row with the row's scale."""
+    from _util import FLT_MAX
+
+    rng = np.random.default_rng(1616)
+    modes = ["E4M3_RNE", "E5M2_STOCHASTIC", "E4M3_STOCHASTIC", "E3M4_STOCHASTIC", "E5M2_RNE"]
+    for case in range(80):
+        mode = modes[int(rng.integers(len(modes)))]
+        fmt, rm = hip.parse_mode(mode)
+        cols = int(rng.choice([8, 16, 24, 64, 200, 512, 1000, 1024, 4096, 8200, 16384, 32768, 65536, 70000]))
+        rows = int(rng.integers(1, max(2, min(300, (1 << 20) // cols))))
+        bf = bool(rng.integers(2))
+        dt = torch.bfloat16 if bf else torch.float16
+        x = (rng.standard_normal((rows, cols)) * np.exp(rng.standard_normal((rows, 1)) * 2)).astype(np.float32)
+        t = torch.from_numpy(x).to(DEV).to(dt)
+        o = torch.empty_like(t)
+        fmax = FLT_MAX[mode.split("_")[0]]
+        hip.set_rng_state((77, 900))
+        hip.quantize_rows_(t, o, rows, fmt, rm, fmax, clamp=True)
+        bits_in = t.view(torch.int16).cpu().numpy().view(np.uint16)
+        got = o.view(torch.int16).cpu().numpy().view(np.uint16)
+        up = t.float().cpu().numpy()
+        for r in sorted(set([0, rows - 1] + [int(v) for v in rng.integers(0, rows, size=4)])):
+            s = orc.scale_from_amax(orc.amax(up[r]), fmax, clamp=True)
+            want = orc.cast16(bits_in[r], bf, mode, scale=s, seed=77, offset=900 + r)
+            assert np.array_equal(got[r], want), "16-bit rows case %d: %s %s %dx%d row %d" % (
+                case, mode, "bf16" if bf else "f16", rows, cols, r)
+
+
+def test_random_gemm_shapes_with_epilogue_maximum(hip):
+    """c-model GEMM over random small shapes, transposes, alpha and accumulate, through the _amax entry point: the
+    matrix against the oracle's chains, the word against the matrix."""
+    rng = np.random.default_rng(909)
+    for case in range(60):
+        M, N, K = (int(rng.integers(1, 400)), int(rng.integers(1, 400)), int(rng.choice([1, 3, 16, 32, 64, 96, 130, 512])))
+        if case % 6 == 0:
+            M, N, K = 4 * int(rng.integers(260, 300)), 4 * int(rng.integers(260, 300)), 32   # the interior + strips split
+        at, bt = bool(rng.integers(2)), bool(rng.integers(2))
+        variant, fused = ((1, True), (0, False))[int(rng.integers(2))]
+        alpha = float(rng.choice([1.0, 0.5, -2.0]))
+        A = rng.standard_normal((K, M) if at else (M, K)).astype(np.float32)
+        B = rng.standard_normal((N, K) if bt else (K, N)).astype(np.float32)
+        C0 = rng.standard_normal((M, N)).astype(np.float32)
+        C = torch.from_numpy(C0).to(DEV)
+        word = torch.zeros(1, dtype=torch.int32, device=DEV)
+        hip.gemm_(C, torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV), alpha, at, bt, variant, amax=word)
+        prod = orc.gemm(A, B, 1.0, at, bt, fused=fused)
+        want = C0 + (np.float32(alpha) * prod + np.float32(0.0) * C0)
+        what = "gemm case %d: %dx%dx%d at=%d bt=%d variant=%d alpha=%g" % (case, M, N, K, at, bt, variant, alpha)
+        assert_bits_equal(C.cpu().numpy(), want, what)
+        assert int(word.item()) == int(np.abs(want).max().view(np.uint32)), what
