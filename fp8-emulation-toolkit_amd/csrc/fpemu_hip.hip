@@ -83,6 +83,8 @@ struct CastParams {
 // 1 GiB (tools/sweep.hip against libraries built with each size): the one-vector-per-lane deterministic cast
 // runs 6.74 / 6.84 / 6.79 TB/s with 256 / 128 / 64 threads -- smaller workgroups retire and are replaced at a
 // finer grain, which keeps more requests in flight; the stochastic cast (four vectors per lane) prefers 256.
+// 16-bit storage, deterministic: 128 as well since the packed quantiser (tools/storage_bench.py against libraries
+// built with 64 / 128 / 256: bf16 at 1 GiB of traffic 6.72 / 6.84 / 6.71 TB/s with one vector per lane).
 #ifndef FPEMU_CAST_BLOCK_DET
 #define FPEMU_CAST_BLOCK_DET 128
 #endif
@@ -90,7 +92,7 @@ struct CastParams {
 #define FPEMU_CAST_BLOCK_SR 256
 #endif
 #ifndef FPEMU_CAST_BLOCK_16
-#define FPEMU_CAST_BLOCK_16 256
+#define FPEMU_CAST_BLOCK_16 128
 #endif
 constexpr int cast_block(int rm, int dt) {
   return rm == STOCHASTIC ? FPEMU_CAST_BLOCK_SR : (dt == FPEMU_F32 ? FPEMU_CAST_BLOCK_DET : FPEMU_CAST_BLOCK_16);
@@ -126,11 +128,13 @@ struct LaneNoise {  // cast_vector's noise source in the flat cast: slot `slot` 
   }
 };
 
-// 16-byte vectors per lane: 4 for stochastic modes (the noise layout's superblock); deterministic fp32
-// storage 1 (pure stream, measured fastest); deterministic 16-bit storage 2 (twice the ALU work per byte:
-// a second independent vector per lane hides it)
+// 16-byte vectors per lane: 4 for stochastic modes (the noise layout's superblock); deterministic casts 1 (pure
+// stream, measured fastest).  16-bit storage held two vectors per lane while its quantiser ran per element; with the
+// packed quantiser the ALU no longer shows (E5M2_RTZ and E4M3_RNE run at the same rate) and the fp32 geometry wins:
+// bf16, 1 GiB of traffic per launch, 6.43 (2 vectors, 256 threads) -> 6.84 TB/s (1 vector, 128 threads), the fp32
+// cast's rate over the same bytes; 4 vectors 6.42, 2 vectors with 128 / 64 threads 6.45 / 6.58.
 #ifndef FPEMU_CAST_U16
-#define FPEMU_CAST_U16 2
+#define FPEMU_CAST_U16 1
 #endif
 constexpr int slots_per_wave(int rm, int dt) { return rm == STOCHASTIC ? 4 : (dt == FPEMU_F32 ? 1 : FPEMU_CAST_U16); }
 
