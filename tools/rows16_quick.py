@@ -24,11 +24,13 @@ def timed(fn, reps=30):
     return e0.elapsed_time(e1) / reps
 
 
-for mode in ("E4M3_RNE", "E5M2_STOCHASTIC"):
+for mode in os.environ.get("MODES", "E4M3_RNE E5M2_STOCHASTIC").split():
     out = []
     x = (torch.randn(n, device="cuda") * 3).to(torch.bfloat16)
     y = torch.empty_like(x)
     f, r = hip.parse_mode(mode)
+    ms = timed(lambda: hip.cast_(x, y, f, r, scale=3.0, seed=1, offset=2))
+    out.append("flat: %.0f" % (4 * n / ms / 1e6))
     for bs in (8, 16, 32, 64, 128, 256, 512, 1024, 4096):
         ms = timed(lambda: hip.quantize_blocks_(x, y, bs, f, r))
         out.append("bn%d: %.0f" % (bs, 4 * n / ms / 1e6))
