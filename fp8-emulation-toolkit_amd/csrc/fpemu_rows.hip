@@ -182,7 +182,7 @@ template <int DT> __device__ __forceinline__ uint32_t absmax16_vector(const u32x
 }
 
 // R = lane groups (rows) per lane: 2 gives 16-bit storage with short rows a second independent vector in flight per
-// lane (twice the ALU work per byte of fp32 storage; the flat cast holds two for the same reason).  Row j of a lane
+// lane (measured per lane-group size, see rows_per_lane below; the flat cast went back to one).  Row j of a lane
 // is in the j-th run of BLOCK >> lg rows of the workgroup's R * (BLOCK >> lg), so a wave's load still covers one
 // contiguous run of rows.
 template <int FMT, int RM, int DT, int NV, int BLOCK, int R = 1>
