@@ -729,16 +729,23 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
     }
 #endif
   } else if constexpr (CHAIN) {
+    // The chains started from these very addresses (chain_start above the k loop).  Left to itself the compiler keeps
+    // that address arithmetic alive across the loop for reuse here, which is what pushed the 128 x 128 kernels past
+    // 256 VGPRs (four dwords spilled before the loop and reloaded every iteration: 126 against 142 TFLOP/s at 8192^3).
+    // Opaque copies of the leading dimension and the lane's coordinates make the epilogue compute its own.
+    int64_t ldc_e = ldc;
+    int li_e = li, lk_e = lk;
+    asm volatile("" : "+s"(ldc_e), "+v"(li_e), "+v"(lk_e));
 #pragma unroll
     for (int i = 0; i < TW; i++)
 #pragma unroll
       for (int j = 0; j < TW; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          const int col = n0 + wn + j * 32 + li;
+          const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk_e;
+          const int col = n0 + wn + j * 32 + li_e;
           if ((FULL || (row < M && col < N)) && (bt.nstore == 0 || col < bt.nstore)) {
-            C[(int64_t)row * ldc + col] = acc[i][j][r];
+            C[(int64_t)row * ldc_e + col] = acc[i][j][r];
             mx = max_u32(mx, abs_bits(acc[i][j][r]));
           }
         }

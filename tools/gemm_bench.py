@@ -43,6 +43,32 @@ def run(M, N, K, at, bt, variant, iters=None):
         variant, M, N, K, at, bt, ms, tf, tf / PEAK[variant]), flush=True)
 
 
+def run_chain(M, N, K, variant=1, iters=20):
+    """fpemu_gemm_chain_f32 (accumulators start at C, C = acc): the CHAIN instantiation of the same kernels."""
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(K, N, device="cuda")
+    C = torch.zeros(M, N, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def go():
+        rc = hip.lib().fpemu_gemm_chain_f32(C.data_ptr(), A.data_ptr(), B.data_ptr(), M, N, K, K, N, N, 0, 0, variant,
+                                            1, 0, 0, 0, 1, 0, 0, st)
+        assert rc == 0, rc
+    for _ in range(5):
+        go()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        go()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * M * N * K / ms / 1e9
+    print("chain variant=%d %5dx%5dx%5d  %8.3f ms  %7.2f TFLOP/s  frac=%.3f" % (variant, M, N, K, ms, tf, tf / PEAK[variant]),
+          flush=True)
+
+
 if __name__ == "__main__":
     sizes = [(4096, 4096, 4096), (8192, 8192, 8192)]
     args = [a for a in sys.argv[1:] if "x" in a]
@@ -52,5 +78,8 @@ if __name__ == "__main__":
     trans = ((False, False),) if "nn" in sys.argv else ((False, False), (False, True), (True, False), (True, True))
     for v in variants:
         for (M, N, K) in sizes:
+            if "chain" in sys.argv:
+                run_chain(M, N, K, v)
+                continue
             for at, bt in trans:
                 run(M, N, K, at, bt, v)
