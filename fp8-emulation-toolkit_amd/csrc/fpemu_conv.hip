@@ -361,36 +361,61 @@ struct PhaseTable {
   const float *plane[16];   // by py * st + px (st <= 4); nullptr: no tap
   int pitch[16], Wh[16];
 };
-// A thread takes the st pixels x = xh * st .. xh * st + st - 1 of a row: one coalesced read per phase plane, st
-// consecutive floats written (one 8-byte store for stride 2 and an even width).
-template <int ST>
-__global__ __launch_bounds__(NT) void interleave_phases(float *__restrict__ gin, PhaseTable tb, int64_t planes, int H, int W,
-                                                        int st_rt) {
+// A lane group of 1 << lg threads takes a row of gin (so the row's plane / y split is one 32-bit division per thread,
+// not two 64-bit ones per element).  Q = 1: a thread takes the st pixels x = xh * st .. xh * st + st - 1: one coalesced
+// read per phase plane, st consecutive floats written (one 8-byte store for stride 2 and an even width).  Q = 2
+// (stride 2, W % 4 == 0, 16-byte aligned gin): two pixels of each of the row's two planes as 8-byte loads, one 16-byte
+// store.
+template <int ST, int Q>
+__global__ __launch_bounds__(NT) void interleave_phases(float *__restrict__ gin, PhaseTable tb, int64_t rows, int H, int W,
+                                                        int st_rt, int lg) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int st = ST ? ST : st_rt;
-  const int Wq = (W + st - 1) / st;
-  const int64_t per_plane = (int64_t)H * Wq, total = planes * per_plane;
-  for (int64_t i = gtid(); i < total; i += gstride()) {
-    const int64_t pl = i / per_plane;
-    const int rem = (int)(i - pl * per_plane);
-    const int y = rem / Wq, xh = rem - y * Wq;
-    const int py = y % st, yh = y / st;
-    float *dst = gin + (pl * H + y) * (int64_t)W + xh * st;
-    float v[ST ? ST : 4];
-#pragma unroll
-    for (int px = 0; px < (ST ? ST : 4); px++) {
-      v[px] = 0.f;
-      if (px < st && xh * st + px < W) {
-        const int p = py * st + px;
-        if (tb.plane[p] != nullptr) v[px] = tb.plane[p][pl * tb.pitch[p] + yh * tb.Wh[p] + xh];
-      }
+  const int64_t row = (int64_t)blockIdx.x * (NT >> lg) + (threadIdx.x >> lg);
+  if (row >= rows) return;
+  const int t = (int)threadIdx.x & ((1 << lg) - 1);
+  int64_t pl;
+  int y;
+  if (rows <= 0x7FFFFFFF) {  // uniform
+    const uint32_t q = (uint32_t)row / (uint32_t)H;
+    pl = q;
+    y = (int)((uint32_t)row - q * (uint32_t)H);
+  } else {
+    pl = row / H;
+    y = (int)(row - pl * H);
+  }
+  const int py = y % st, yh = y / st;
+  float *dst = gin + row * (int64_t)W;
+  if constexpr (Q == 2) {
+    const float *p0 = tb.plane[py * 2], *p1 = tb.plane[py * 2 + 1];
+    if (p0 != nullptr) p0 += pl * tb.pitch[py * 2] + yh * tb.Wh[py * 2];
+    if (p1 != nullptr) p1 += pl * tb.pitch[py * 2 + 1] + yh * tb.Wh[py * 2 + 1];
+    for (int u = t; u < W / 4; u += 1 << lg) {
+      f32x2 a = {0.f, 0.f}, b = {0.f, 0.f};
+      if (p0 != nullptr) a = *reinterpret_cast<const f32x2 *>(p0 + 2 * u);
+      if (p1 != nullptr) b = *reinterpret_cast<const f32x2 *>(p1 + 2 * u);
+      *reinterpret_cast<f32x4 *>(dst + 4 * u) = f32x4{a[0], b[0], a[1], b[1]};
     }
-    if (ST == 2 && (W & 1) == 0 && ((uintptr_t)gin & 7u) == 0) {
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      *reinterpret_cast<f32x2 *>(dst) = f32x2{v[0], v[1]};
-    } else {
+  } else {
+    const int Wq = (W + st - 1) / st;
+    const bool pair = ST == 2 && (W & 1) == 0 && ((uintptr_t)gin & 7u) == 0;
+    for (int xh = t; xh < Wq; xh += 1 << lg) {
+      float v[ST ? ST : 4];
 #pragma unroll
-      for (int px = 0; px < (ST ? ST : 4); px++)
-        if (px < st && xh * st + px < W) dst[px] = v[px];
+      for (int px = 0; px < (ST ? ST : 4); px++) {
+        v[px] = 0.f;
+        if (px < st && xh * st + px < W) {
+          const int p = py * st + px;
+          if (tb.plane[p] != nullptr) v[px] = tb.plane[p][pl * tb.pitch[p] + yh * tb.Wh[p] + xh];
+        }
+      }
+      if (pair) {
+        *reinterpret_cast<f32x2 *>(dst + xh * 2) = f32x2{v[0], v[1]};
+      } else {
+#pragma unroll
+        for (int px = 0; px < (ST ? ST : 4); px++)
+          if (px < st && xh * st + px < W) dst[xh * st + px] = v[px];
+      }
     }
   }
 }
@@ -975,10 +1000,22 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
         tb.plane[p] = plane; tb.pitch[p] = ph.pitch; tb.Wh[p] = ph.Wh;
         plane += nb * C * ph.pitch;
       }
-      hipLaunchKernelGGL(st == 2 ? interleave_phases<2> : interleave_phases<0>,
-                         dim3(blocks_for(nb * C * H * ((W + st - 1) / st))), dim3(NT), 0, s, gin + n0 * C * HW, tb, nb * C,
-                         (int)H, (int)W, st);
-      CHECK_LAUNCH(who);
+      {
+        float *gdst = gin + n0 * C * HW;
+        bool quad = st == 2 && W % 4 == 0 && ((uintptr_t)gdst % 16u) == 0;
+        for (int p = 0; p < 4 && quad; p++)   // 8-byte loads: every plane row starts on an even element
+          quad = tb.plane[p] == nullptr || (tb.pitch[p] % 2 == 0 && tb.Wh[p] % 2 == 0 && ((uintptr_t)tb.plane[p] % 8u) == 0);
+        const int64_t units = quad ? W / 4 : (W + st - 1) / st, rows_g = nb * C * H;
+        int lg = 0;
+        while (lg < 8 && (1 << lg) < units) lg++;
+        const int64_t nblk = (rows_g + (NT >> lg) - 1) / (NT >> lg);
+        if (nblk > 0x7FFFFFFF) return fail(who, FPEMU_EINVAL, "more than 2^31-1 workgroups");
+        void (*ik)(float *, PhaseTable, int64_t, int, int, int, int) = interleave_phases<0, 1>;
+        if (quad) ik = interleave_phases<2, 2>;
+        else if (st == 2) ik = interleave_phases<2, 1>;
+        hipLaunchKernelGGL(ik, dim3((unsigned)nblk), dim3(NT), 0, s, gdst, tb, rows_g, (int)H, (int)W, st, lg);
+        CHECK_LAUNCH(who);
+      }
     }
     return FPEMU_OK;
   }
