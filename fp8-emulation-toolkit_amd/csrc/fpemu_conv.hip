@@ -446,8 +446,16 @@ __global__ __launch_bounds__(NT) void pad_planes(const float *__restrict__ x, fl
   const int64_t plane = (int64_t)Hp * Wp, total = planes * plane;
   for (int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 4; i < total; i += (int64_t)pad_blocks * NT * 4) {
     f32x4 o;
-    int64_t pl = i / plane;
-    int rem = (int)(i - pl * plane);
+    int64_t pl;
+    int rem;
+    if (total <= 0x7FFFFFFF) {  // uniform: one 32-bit division instead of a 64-bit one per vector
+      const uint32_t q = (uint32_t)i / (uint32_t)plane;
+      pl = q;
+      rem = (int)((uint32_t)i - q * (uint32_t)plane);
+    } else {
+      pl = i / plane;
+      rem = (int)(i - pl * plane);
+    }
     int y = rem / Wp, xx = rem - y * Wp;
 #pragma unroll
     for (int e = 0; e < 4; e++) {

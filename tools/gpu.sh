@@ -95,6 +95,14 @@ conv)       # one convolution shape of tools/conv_bench.py (default 1 = 3x3, 64 
   pmc $P/pmc_write WRITE_SIZE python3 tools/conv_bench.py $SHAPE
   $S kstats $P/stats; $S hbm $P
   ;;
+conv-kernels) # per-kernel durations of several conv_bench shapes (SHAPES="0 1 5 6 9"): where the helpers stand beside the GEMMs
+  for SHAPE in ${SHAPES:-0 1 5 6 9}; do
+    P=gpurun_out/convk_$SHAPE
+    stats $P 200 python3 tools/conv_bench.py $SHAPE
+    echo "== shape $SHAPE: $(grep '^N' $P/run.log)"
+    $S kstats $P --top 12
+  done
+  ;;
 conv-pmc)   # SQ counters of the convolution's GEMM kernel (KERNEL=substring to pick another), three passes
   SHAPE=${1:-1}; P=gpurun_out/conv_pmc_$SHAPE
   pmc $P/a "$SQ_A" python3 tools/conv_bench.py $SHAPE
