@@ -346,16 +346,21 @@ __global__ __launch_bounds__(NT) void gemm_seqk_kernel(Operand A, Operand B, flo
 
   const int M = A.R, N = B.R;
   uint32_t mx = 0u;  // max |stored value| (Batch.amax)
+  // CHAIN: the chains started from these addresses; opaque copies keep that arithmetic from staying alive across the k
+  // loop (see gemm_mfma_body's epilogue: 136-140 VGPRs -> the non-chain kernel's 113-118, four waves per SIMD again)
+  int64_t ldc_e = ldc;
+  int ty_e = ty, tx_e = tx;
+  if constexpr (CHAIN) asm volatile("" : "+s"(ldc_e), "+v"(ty_e), "+v"(tx_e));
 #pragma unroll
   for (int ih = 0; ih < H; ih++)
 #pragma unroll
     for (int ii = 0; ii < 4; ii++) {
-      const int r = m0 + ih * 64 + ty * 4 + ii;
+      const int r = m0 + ih * 64 + ty_e * 4 + ii;
       if (r >= M) continue;
 #pragma unroll
       for (int jh = 0; jh < H; jh++) {
-        const int c = n0 + jh * 64 + tx * 4;
-        float *dst = C + (int64_t)r * ldc + c;
+        const int c = n0 + jh * 64 + tx_e * 4;
+        float *dst = C + (int64_t)r * ldc_e + c;
         if constexpr (CHAIN) {
 #pragma unroll
           for (int jj = 0; jj < 4; jj++)
