@@ -192,3 +192,40 @@ def test_random_gemm_shapes_with_epilogue_maximum(hip):
         what = "gemm case %d: %dx%dx%d at=%d bt=%d variant=%d alpha=%g" % (case, M, N, K, at, bt, variant, alpha)
         assert_bits_equal(C.cpu().numpy(), want, what)
         assert int(word.item()) == int(np.abs(want).max().view(np.uint32)), what
+
+
+def test_random_conv_shapes_vs_oracle(hip):
+    """c-model convolution over random geometries -- channel counts on both sides of the 64-channel blocks and of the
+    few-channel backward kernel, strides 1-4 (backward-data by phase of the stride, widths that do and do not take
+    the 16-byte interleave), rectangular images and filters, padding 0-2 -- forward, backward-data and weight update
+    against the oracle's serial chains, both rounding variants."""
+    rng = np.random.default_rng(4242)
+    done = 0
+    while done < 40:
+        N = int(rng.integers(1, 4))
+        C = int(rng.choice([1, 3, 4, 5, 8, 24, 64, 128, 192]))   # <= 64 or a multiple of 64 (the reference's packing)
+        K = int(rng.choice([1, 4, 8, 20, 64, 128]))
+        R, S = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        st = int(rng.choice([1, 1, 2, 2, 3, 4]))
+        pd = int(rng.integers(0, 3))
+        H, W = int(rng.integers(4, 23)), int(rng.choice([4, 7, 8, 10, 12, 13, 16, 20, 21]))
+        if H + 2 * pd < R or W + 2 * pd < S:
+            continue
+        OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
+        variant, fused = ((1, True), (0, False))[done % 2]
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        w = (rng.standard_normal((K, C, R, S)) * 0.3).astype(np.float32)
+        b = rng.standard_normal(K).astype(np.float32)
+        go = rng.standard_normal((N, K, OH, OW)).astype(np.float32)
+        tx, tw, tgo = (torch.from_numpy(a).to(DEV) for a in (x, w, go))
+        y = torch.empty(go.shape, device=DEV)
+        hip.conv2d_fp_(y, tx, tw, torch.from_numpy(b).to(DEV), st, pd, variant)
+        gi = torch.full(x.shape, 7.0, device=DEV)
+        hip.conv2d_bp_(gi, tgo, tw, st, pd, variant)
+        gw = torch.full(w.shape, 7.0, device=DEV)
+        hip.conv2d_wu_(gw, tgo, tx, st, pd, variant)
+        what = "conv case %d: N%d C%d %dx%d K%d %dx%d s%d p%d variant %d" % (done, N, C, H, W, K, R, S, st, pd, variant)
+        assert_bits_equal(y.cpu().numpy(), orc.conv2d_fp(x, w, b, st, pd, fused), what + " fp")
+        assert_bits_equal(gi.cpu().numpy(), orc.conv2d_bp(go, w, (H, W), st, pd, fused), what + " bp")
+        assert_bits_equal(gw.cpu().numpy(), orc.conv2d_wu(go, x, (R, S), st, pd, fused), what + " wu")
+        done += 1
