@@ -28,7 +28,7 @@ def timed(f, launches=20):
 
 
 n = 1 << 27
-for dt, bpe in ((torch.float32, 8), (torch.float16, 4), (torch.bfloat16, 4)):
+for dt, bpe in ((torch.float32, 8), (torch.float16, 4), (torch.bfloat16, 4), (torch.float64, 16)):
     x = (torch.randn(n, device="cuda") * 3).to(dt)
     y = torch.empty_like(x)
     for mode in os.environ.get("MODES", "E4M3_RNE E5M2_STOCHASTIC").split():
