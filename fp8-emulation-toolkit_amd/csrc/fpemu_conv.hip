@@ -36,6 +36,9 @@
 
 extern "C" void fpemu_set_error_(const char *msg);
 extern "C" int fpemu_gemm_tile_edge_(int64_t M, int64_t N, int64_t batch, int variant);
+extern "C" int fpemu_gemm_chain_group_launch_(int count, float *const *C, const float *const *A, const float *const *B,
+                                              const int64_t *K, int64_t M, int64_t N, int64_t batch, int64_t stride_c,
+                                              int variant, void *stream);
 extern "C" int fpemu_gemm_chain_start_launch_(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
                                               int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans,
                                               int variant, int64_t batch, int64_t stride_a, int64_t stride_b,
@@ -274,8 +277,10 @@ struct Phase {
 };
 
 // All phases of a call that have taps and pixels, with where their packed weights and gathered matrices live: ONE
-// pack launch and ONE gather launch (blockIdx.y / .z = phase) instead of one of each per phase -- thirteen launches per
-// 3 x 3 stride-2 backward-data call became seven.
+// pack launch and ONE gather launch (blockIdx.y / .z = phase), ONE grouped launch for the phases' GEMMs where they share
+// their shape (fpemu_gemm_chain_group_launch_), one interleave: thirteen launches per 3 x 3 stride-2 backward-data call
+// became four.  (Folding the pack into the gather launch as an extra grid slice was measured: nothing at C128 / C256,
+// 0.171 -> 0.184 ms at C512 14 x 14, where the weights are the larger job and the gather's grid is small.)
 struct PhaseSet {
   Phase ph[16];
   int64_t woff[16];   // floats from the start of the packed-weight area
@@ -284,12 +289,11 @@ struct PhaseSet {
 };
 
 // Wph[c][(ob, aj, ai, o2)] = w[ob*KB + o2][c][kj][ki], kj = kj0 + (nj - 1 - aj) * st (descending), ki = ki0 + ai * st
-__global__ __launch_bounds__(NT) void pack_w_bp_phase(const float *__restrict__ w, float *__restrict__ Wm_, Geo g, PhaseSet ps) {
-  const Phase ph = ps.ph[blockIdx.y];
-  float *Wm = Wm_ + ps.woff[blockIdx.y];
+__device__ __forceinline__ void pack_w_bp_phase_body(const float *__restrict__ w, float *__restrict__ Wm, const Geo &g,
+                                                     const Phase &ph, int64_t first, int64_t step) {
   const int64_t krs = g.K * ph.nj * ph.ni, total = g.C * krs;
   const int st = (int)g.stride;
-  for (int64_t i = gtid(); i < total; i += gstride()) {
+  for (int64_t i = first; i < total; i += step) {
     const int64_t c = i / krs;
     int64_t kk = i % krs;
     const int64_t o2 = kk % g.KB; kk /= g.KB;
@@ -299,6 +303,10 @@ __global__ __launch_bounds__(NT) void pack_w_bp_phase(const float *__restrict__ 
     const int64_t kj = ph.kj0 + (ph.nj - 1 - aj) * st, ki = ph.ki0 + ai * st;
     Wm[i] = w[(((ob * g.KB + o2) * g.C + c) * g.R + kj) * g.S + ki];
   }
+}
+
+__global__ __launch_bounds__(NT) void pack_w_bp_phase(const float *__restrict__ w, float *__restrict__ Wm_, Geo g, PhaseSet ps) {
+  pack_w_bp_phase_body(w, Wm_ + ps.woff[blockIdx.y], g, ps.ph[blockIdx.y], gtid(), gstride());
 }
 
 // colsp[n][(ob, aj, ai, o2)][(yh, xh)] = gout[n][ob*KB + o2][yh + dj][xh + di] (0 outside), rows of ph.pitch floats
@@ -996,15 +1004,41 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
       }
       PhaseTable tb;
       for (int p = 0; p < 16; p++) { tb.plane[p] = nullptr; tb.pitch[p] = 0; tb.Wh[p] = 1; }
+      // the phases' GEMMs: one grouped launch when they share their shape but for the depth (even H and W, stride 2),
+      // else one launch each
+      float *gc[4];
+      const float *ga[4], *gb[4];
+      int64_t gk[4];
+      bool same = ps.count >= 2 && ps.count <= 4;
+      {
+        float *pl = plane;
+        for (int p = 0, i = 0; p < st * st; p++) {
+          const int q = slot_of[p];
+          if (q < 0) continue;
+          const Phase &ph = ps.ph[q];
+          if (i < 4) { gc[i] = pl; ga[i] = Wm + ps.woff[q]; gb[i] = gath + pc.goff[q]; gk[i] = K * ph.nj * ph.ni; }
+          same = same && ph.pitch == ps.ph[0].pitch;
+          i++;
+          pl += nb * C * ph.pitch;
+        }
+      }
+      int grouped = -100;   // -100: not grouped (the problems do not qualify)
+      if (same) {
+        grouped = fpemu_gemm_chain_group_launch_(ps.count, gc, ga, gb, gk, C, ps.ph[0].pitch, nb, C * ps.ph[0].pitch, variant,
+                                                 stream);
+        if (grouped != FPEMU_OK && grouped != -100) return grouped;
+      }
       for (int p = 0; p < st * st; p++) {
         const int q = slot_of[p];
         if (q < 0) continue;
         const Phase &ph = ps.ph[q];
         const int64_t krs_p = K * ph.nj * ph.ni;
-        rc = fpemu_gemm_chain_start_launch_(plane, Wm + ps.woff[q], gath + pc.goff[q], C, ph.pitch, krs_p, krs_p, ph.pitch,
-                                            ph.pitch, 0, 0, variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3, nullptr,
-                                            0, nullptr, stream);
-        if (rc != FPEMU_OK) return rc;
+        if (grouped != FPEMU_OK) {
+          rc = fpemu_gemm_chain_start_launch_(plane, Wm + ps.woff[q], gath + pc.goff[q], C, ph.pitch, krs_p, krs_p, ph.pitch,
+                                              ph.pitch, 0, 0, variant, nb, 0, krs_p * ph.pitch, C * ph.pitch, 1, 0, 0, 3,
+                                              nullptr, 0, nullptr, stream);
+          if (rc != FPEMU_OK) return rc;
+        }
         tb.plane[p] = plane; tb.pitch[p] = ph.pitch; tb.Wh[p] = ph.Wh;
         plane += nb * C * ph.pitch;
       }

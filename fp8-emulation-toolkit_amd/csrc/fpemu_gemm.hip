@@ -790,6 +790,31 @@ void gemm_mfma_kernel(Operand A, Operand B, float *C, int64_t ldc, float alpha, 
   gemm_mfma_body<A_KCONT, B_KCONT, CHAIN, FULL, TW, false>(A, B, C, ldc, alpha, beta, tiles_m, tiles_n, bt, ConvMap{});
 }
 
+// Up to kGroupMax chain GEMMs that share M, N, the leading dimensions of B and C and the batch, but not their depth, in
+// ONE launch (blockIdx.z = problem): the phases of a strided backward-data convolution are four such problems of 17-46 us
+// each, and a launch of a few hundred short workgroups spends ~8 us ramping up and draining.  Whole tiles only (the
+// unchecked kernel), A row-major M x K_g (k contiguous), B row-major K_g x N, chains start at +0.
+constexpr int kGroupMax = 4;
+struct GroupTab {
+  const float *a[kGroupMax];
+  const float *b[kGroupMax];
+  float *c[kGroupMax];
+  int k[kGroupMax];
+};
+template <int TW>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FPEMU_GEMM_WAVES)))
+void gemm_mfma_group_kernel(Operand A, Operand B, int64_t ldc, int tiles_m, int tiles_n, Batch bt, GroupTab gt) {
+  const int g = blockIdx.z;   // uniform: scalar loads from the kernel arguments
+  const int k = gt.k[g];
+  A.p = gt.a[g];
+  A.K = k;
+  A.ld = k;
+  B.p = gt.b[g];
+  B.K = k;
+  bt.sb = (int64_t)k * B.ld;
+  gemm_mfma_body<true, false, true, true, TW, false>(A, B, gt.c[g], ldc, 1.0f, 0.0f, tiles_m, tiles_n, bt, ConvMap{});
+}
+
 // The implicit convolution's form: A = packed weights [M][segments * 64] (k contiguous), B = padded image planes
 // ([64 channels][plane], positions contiguous), whole tiles only.
 #ifdef FPEMU_GEMM_TRACE  // tuning builds (tools/conv_trace.py): per-workgroup start / end time (100 MHz) and hardware id
@@ -1671,6 +1696,49 @@ extern "C" int fpemu_gemm_chain_f32(float *C, const float *A, const float *B, in
 // fpemu_gemm_chain_f32 with the chains' starting values given instead of read from C (library-internal, used by
 // fpemu_conv.hip's gathered forms): start 1 = init[row], 2 = init[row] + 0.0f, 3 = +0 (init unused).  C is only written,
 // and only its first nstore columns when nstore != 0 (Batch.nstore).
+// Internal to the library (fpemu_conv.hip): `count` (<= 4) chain GEMMs C_g[b] = chain from +0 of A_g (M x K_g, k
+// contiguous, shared by the batch) times B_g[b] (K_g x N, ld = N, batch stride K_g * N), C_g[b] at stride_c, in one
+// launch.  Returns FPEMU_OK, an error, or -100 when the problems do not qualify (ragged tiles, small-tile shapes, the
+// VALU variant): the caller then launches them one by one.
+extern "C" int fpemu_gemm_chain_group_launch_(int count, float *const *C, const float *const *A, const float *const *B,
+                                              const int64_t *K, int64_t M, int64_t N, int64_t batch, int64_t stride_c,
+                                              int variant, void *stream) {
+  if (count < 2 || count > kGroupMax || variant != 1 || M <= 0 || N <= 0 || batch <= 0 || batch > 65535) return -100;
+  const int tb = fpemu_gemm_tile_edge_(M, N, batch, variant);   // the edge the phases' pitch was padded to
+  if (tb < 64 || M % tb || N % tb || N % 4 || stride_c % 4 || M > 0x7FFFFFFF || N > 0x7FFFFFFF) return -100;
+  GroupTab gt;
+  for (int g = 0; g < kGroupMax; g++) { gt.a[g] = nullptr; gt.b[g] = nullptr; gt.c[g] = nullptr; gt.k[g] = 0; }
+  // deepest problem first: its workgroups are the long ones, the short ones fill in behind them
+  int order[kGroupMax];
+  for (int g = 0; g < count; g++) order[g] = g;
+  for (int i = 1; i < count; i++)
+    for (int j = i; j > 0 && K[order[j]] > K[order[j - 1]]; j--) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  for (int i = 0; i < count; i++) {
+    const int g = order[i];
+    if (K[g] <= 0 || K[g] % MBK || K[g] > 0x7FFFFFFF || !aligned16(A[g]) || !aligned16(B[g]) || !aligned16(C[g]) ||
+        (K[g] * N) % 4)
+      return -100;
+    gt.a[i] = A[g]; gt.b[i] = B[g]; gt.c[i] = C[g]; gt.k[i] = (int)K[g];
+  }
+  const int tiles_m = (int)(M / tb), tiles_n = (int)(N / tb);
+  if ((int64_t)tiles_m * tiles_n > 0x7FFFFFFF) return -100;
+  Operand a, b;
+  a.p = nullptr; a.ld = 0; a.R = (int)M; a.K = 0; a.vec = 1; a.pad = -0.0f;
+  b.p = nullptr; b.ld = N; b.R = (int)N; b.K = 0; b.vec = 1; b.pad = 0.0f;
+  Batch bt{0, 0, stride_c, 0, 0, 1, 3, nullptr, 0, nullptr};
+  const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)batch, (unsigned)count);
+  if (tb == 64)
+    hipLaunchKernelGGL(gemm_mfma_group_kernel<1>, grid, dim3(NT), 0, (hipStream_t)stream, a, b, N, tiles_m, tiles_n, bt, gt);
+  else
+    hipLaunchKernelGGL(gemm_mfma_group_kernel<2>, grid, dim3(NT), 0, (hipStream_t)stream, a, b, N, tiles_m, tiles_n, bt, gt);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fpemu_set_error_(hipGetErrorString(e));
+    return (int)e;
+  }
+  return FPEMU_OK;
+}
+
 extern "C" int fpemu_gemm_chain_start_launch_(float *C, const float *A, const float *B, int64_t M, int64_t N, int64_t K,
                                               int64_t lda, int64_t ldb, int64_t ldc, int a_trans, int b_trans,
                                               int variant, int64_t batch, int64_t stride_a, int64_t stride_b,

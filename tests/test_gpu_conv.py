@@ -73,6 +73,9 @@ def test_conv_vs_reference_fixture(hip, bname, variant, fused):
                                   # a stride larger than the filter's reach
                                   (2, 8, 11, 13, 16, 5, 5, 3, 2), (1, 8, 9, 9, 8, 1, 1, 4, 0), (2, 16, 10, 10, 16, 2, 2, 2, 0),
                                   (1, 8, 9, 11, 8, 3, 3, 2, 0), (2, 64, 9, 9, 64, 2, 2, 3, 1),
+                                  # ... enough 64 x 64 tiles for the large-tile kernels: the four phases' GEMMs as ONE
+                                  # grouped launch (test_strided_bp_takes_the_grouped_launch pins the tile edge)
+                                  (16, 128, 40, 40, 64, 3, 3, 2, 1),
                                   # weight update on the large-tile kernels with OH*OW = 196 not a multiple of 32: both
                                   # operands padded to 224 (the separate-rounding variant pads in most cases above)
                                   (3, 256, 14, 14, 256, 3, 3, 1, 1)])
@@ -324,3 +327,15 @@ def test_hooked_conv_output_quantised_from_the_epilogue_maximum(hip, monkeypatch
     q = lambda a: orc.cast(a, "E4M3_RNE", scale=orc.scale_from_amax(orc.amax(a), 448.0))
     out = orc.conv2d_fp(q(x.cpu().numpy()), q(w0.cpu().numpy()), conv.bias.detach().cpu().numpy(), 1, 1, True)
     assert_bits_equal(y_fast.cpu().numpy(), q(out), "hooked conv output")
+
+
+def test_strided_bp_takes_the_grouped_launch(hip):
+    """The case (16, 128, 40, 40, 64, 3, 3, 2, 1) of test_conv_vs_oracle is there for the grouped launch of the phases'
+    GEMMs (fpemu_gemm_chain_group_launch_): it needs the large-tile kernels, i.e. a tile edge of at least 64 for the
+    128 x 448 (400 pixels per phase, padded) x 16-image problems, and whole tiles."""
+    L = hip.lib()
+    import ctypes
+    L.fpemu_gemm_tile_edge_.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
+    L.fpemu_gemm_tile_edge_.restype = ctypes.c_int
+    edge = L.fpemu_gemm_tile_edge_(128, 400, 16, 1)
+    assert edge >= 64 and 128 % edge == 0

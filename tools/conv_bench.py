@@ -28,18 +28,19 @@ def timed(fn, iters=3):
     return e0.elapsed_time(e1) / iters
 
 
-sel = [int(a) for a in sys.argv[1:]]
-for (N, C, H, W, K, R, S, st, pd) in ([LAYERS[i] for i in sel] if sel else LAYERS):
-    OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
-    x = torch.randn(N, C, H, W, device="cuda")
-    w = torch.randn(K, C, R, S, device="cuda")
-    b = torch.randn(K, device="cuda")
-    go = torch.randn(N, K, OH, OW, device="cuda")
-    y, gi, gw = torch.empty_like(go), torch.empty_like(x), torch.empty_like(w)
-    flop = 2.0 * N * K * C * R * S * OH * OW
-    t_fp = timed(lambda: hip.conv2d_fp_(y, x, w, b, st, pd))
-    t_bp = timed(lambda: hip.conv2d_bp_(gi, go, w, st, pd))
-    t_wu = timed(lambda: hip.conv2d_wu_(gw, go, x, st, pd))
-    print("N%d C%d %dx%d K%d %dx%d s%d p%d  %.2f GFLOP | fp %.3f ms (%.1f TF) | bp %.3f ms (%.1f TF) | wu %.3f ms (%.1f TF)" % (
-        N, C, H, W, K, R, S, st, pd, flop / 1e9, t_fp, flop / t_fp / 1e9, t_bp, flop / t_bp / 1e9, t_wu,
-        flop / t_wu / 1e9), flush=True)
+if __name__ == "__main__":
+    sel = [int(a) for a in sys.argv[1:]]
+    for (N, C, H, W, K, R, S, st, pd) in ([LAYERS[i] for i in sel] if sel else LAYERS):
+        OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
+        x = torch.randn(N, C, H, W, device="cuda")
+        w = torch.randn(K, C, R, S, device="cuda")
+        b = torch.randn(K, device="cuda")
+        go = torch.randn(N, K, OH, OW, device="cuda")
+        y, gi, gw = torch.empty_like(go), torch.empty_like(x), torch.empty_like(w)
+        flop = 2.0 * N * K * C * R * S * OH * OW
+        t_fp = timed(lambda: hip.conv2d_fp_(y, x, w, b, st, pd))
+        t_bp = timed(lambda: hip.conv2d_bp_(gi, go, w, st, pd))
+        t_wu = timed(lambda: hip.conv2d_wu_(gw, go, x, st, pd))
+        print("N%d C%d %dx%d K%d %dx%d s%d p%d  %.2f GFLOP | fp %.3f ms (%.1f TF) | bp %.3f ms (%.1f TF) | wu %.3f ms (%.1f TF)" % (
+            N, C, H, W, K, R, S, st, pd, flop / 1e9, t_fp, flop / t_fp / 1e9, t_bp, flop / t_bp / 1e9, t_wu,
+            flop / t_wu / 1e9), flush=True)
