@@ -203,6 +203,45 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
   }
 }
 
+// Short rows that are not whole vectors (7 x 7 outputs: 49 pixels): cols_fp's scalar path gives a 256-thread block to
+// one 196-byte row at a time (C512 7 x 7 at batch 32: 147 456 rows, 92 us for 29 MB -- 40 % of that layer's weight
+// update).  Here a row gets 1 << LG lanes (the smallest power of two covering its pitch, up to 128) and a block takes
+// NT >> LG consecutive rows per trip; the row's tap is decoded per thread (three 32-bit divisions per row, not per pixel).
+template <int LG>
+__global__ __launch_bounds__(NT) void cols_fp_short(const float *__restrict__ x, float *__restrict__ cols, Geo g,
+                                                    int64_t nrows, int rows_per_img, int pitch) {
+  constexpr int LPR = 1 << LG, RPB = NT >> LG;
+  const int P = (int)(g.OH * g.OW), OW = (int)g.OW, H = (int)g.H, W = (int)g.W, st = (int)g.stride;
+  const int crs = (int)(g.C * g.R * g.S);
+  const int64_t HW = (int64_t)H * W;
+  const int lane = (int)threadIdx.x & (LPR - 1), rl = (int)threadIdx.x >> LG;
+  for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < nrows; row0 += (int64_t)gridDim.x * RPB) {
+    int64_t n = row0 / rows_per_img;                   // uniform over the block
+    int kk = (int)(row0 - n * rows_per_img) + rl;
+    while (kk >= rows_per_img) { kk -= rows_per_img; n++; }
+    const int64_t row = row0 + rl;
+    if (row >= nrows) continue;
+    float *dst = cols + row * pitch;
+    const bool real = kk < crs;                        // else: a zero row that pads the chain to whole k tiles
+    int k2 = real ? kk : 0;
+    const int c2 = k2 % (int)g.CB; k2 /= (int)g.CB;
+    const int ki = k2 % (int)g.S; k2 /= (int)g.S;
+    const int kj = k2 % (int)g.R;
+    const int cb = k2 / (int)g.R;
+    const float *src = x + (n * g.C + cb * g.CB + c2) * HW;
+    const int y0 = kj - (int)g.pad, x0 = ki - (int)g.pad;
+    for (int p = lane; p < pitch; p += LPR) {
+      float v = 0.f;
+      if (real && p < P) {
+        const int oj = p / OW, oi = p - oj * OW;
+        const int y = oj * st + y0, xx = oi * st + x0;
+        if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = src[y * W + xx];
+      }
+      dst[p] = v;
+    }
+  }
+}
+
 typedef void (*cols_fp_fn)(const float *, float *, Geo, int64_t, int, int);
 cols_fp_fn pick_cols_fp(bool vec4, int64_t stride, bool rb4) {
   if (!vec4) return cols_fp<false, 0, 1>;
@@ -676,6 +715,27 @@ unsigned blocks_for(int64_t total) {
   return b < 1 ? 1u : (unsigned)b;
 }
 
+// The forward / weight-update gather of `nrows` rows (rows_per_img per image) of `pitch` floats.
+void launch_cols_fp(const float *x, float *cols, const Geo &g, int64_t nrows, int64_t rows_per_img, int64_t pitch,
+                    int64_t stride, hipStream_t s) {
+  const int64_t P = g.OH * g.OW;
+  const bool v4 = P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, rb4 = v4 && g.CB % 4 == 0 && rows_per_img % 4 == 0;
+  if (!v4 && pitch <= 128) {
+    int lg = 3;
+    while ((1 << lg) < pitch) lg++;
+    const int64_t rpb = NT >> lg;
+    int64_t blocks = (nrows + rpb - 1) / rpb;
+    if (blocks > 1048576) blocks = 1048576;
+    if (blocks < 1) blocks = 1;
+    cols_fp_fn fn = lg == 3 ? cols_fp_short<3> : lg == 4 ? cols_fp_short<4> : lg == 5 ? cols_fp_short<5>
+                  : lg == 6 ? cols_fp_short<6> : cols_fp_short<7>;
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(NT), 0, s, x, cols, g, nrows, (int)rows_per_img, (int)pitch);
+    return;
+  }
+  hipLaunchKernelGGL(pick_cols_fp(v4, stride, rb4), gather_grid(P, nrows / (rb4 ? 4 : 1)), dim3(NT), 0, s, x, cols, g, nrows,
+                     (int)rows_per_img, (int)pitch);
+}
+
 int fail(const char *who, int code, const char *what) {
   char msg[200];
   snprintf(msg, sizeof(msg), "%s: %s", who, what);
@@ -896,9 +956,7 @@ static int conv2d_fp_impl(const char *who, float *out, const float *in, const fl
   const int start = bias == nullptr ? 3 : C % 64 != 0 ? 2 : 1;
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    const bool v4 = P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, rb4 = v4 && g.CB % 4 == 0;   // (kp is a multiple of 32)
-    hipLaunchKernelGGL(pick_cols_fp(v4, stride, rb4), gather_grid(P, nb * kp / (rb4 ? 4 : 1)),
-                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * kp, (int)kp, (int)Pp);
+    launch_cols_fp(in + n0 * C * H * W, cols, g, nb * kp, kp, Pp, stride, s);   // (kp is a multiple of 32)
     CHECK_LAUNCH(who);
     rc = fpemu_gemm_chain_start_launch_(out + n0 * K * P, Wm, cols, K, Pp, kp, kp, Pp, P, 0, 0, variant, nb, 0, kp * Pp,
                                         K * P, 1, 0, 0, start, bias, Pp != P ? P : 0, amax, stream);
@@ -1097,9 +1155,7 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
   }
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
-    const bool v4 = P % 4 == 0 && ((uintptr_t)cols % 16u) == 0, rb4 = v4 && g.CB % 4 == 0;   // (then crs is a multiple of 4)
-    hipLaunchKernelGGL(pick_cols_fp(v4, stride, rb4), gather_grid(P, nb * crs / (rb4 ? 4 : 1)),
-                       dim3(NT), 0, s, in + n0 * C * H * W, cols, g, nb * crs, (int)crs, (int)Pp);
+    launch_cols_fp(in + n0 * C * H * W, cols, g, nb * crs, crs, Pp, stride, s);
     CHECK_LAUNCH(who);
     const float *ga = gout + n0 * K * P;
     if (Pp != P) {  // rows of gout with a tail of -0 up to whole k tiles (behind the chunk's gathered rows)
