@@ -62,51 +62,75 @@ __device__ __forceinline__ int64_t gstride() { return (int64_t)gridDim.x * NT; }
 
 // Wfp[k][(cb, kj, ki, c2)] = w[k][cb*CB + c2][kj][ki], rows of KP floats (zeros behind the C*R*S weights)
 // (first / step: this thread's share of a launch)
+// (the index type I is uint32_t when the tensor has fewer than 2^31 elements: five 32-bit divisions per element instead
+// of five 64-bit ones -- C512 3 x 3: 12 -> ~5 us)
+template <class I>
+__device__ __forceinline__ void pack_w_fp_body_t(const float *__restrict__ w, float *__restrict__ Wm, const Geo &g,
+                                                 int64_t first, int64_t step) {
+  const I C = (I)g.C, R = (I)g.R, S = (I)g.S, CB = (I)g.CB, KP = (I)g.KP;
+  const I crs = C * R * S, total = (I)g.K * KP;
+  for (I i = (I)first; i < total; i += (I)step) {
+    const I k = i / KP;
+    I kk = i - k * KP;
+    if (kk >= crs) { Wm[i] = -0.0f; continue; }   // times the zero rows of cols: -0, which leaves any sum as it is
+    const I c2 = kk % CB; kk /= CB;
+    const I ki = kk % S; kk /= S;
+    const I kj = kk % R;
+    const I cb = kk / R;
+    Wm[i] = w[((k * C + cb * CB + c2) * R + kj) * S + ki];
+  }
+}
 __device__ __forceinline__ void pack_w_fp_body(const float *__restrict__ w, float *__restrict__ Wm, const Geo &g,
                                                int64_t first, int64_t step) {
-  const int64_t crs = g.C * g.R * g.S, total = g.K * g.KP;
-  for (int64_t i = first; i < total; i += step) {
-    const int64_t k = i / g.KP;
-    int64_t kk = i % g.KP;
-    if (kk >= crs) { Wm[i] = -0.0f; continue; }   // times the zero rows of cols: -0, which leaves any sum as it is
-    const int64_t c2 = kk % g.CB; kk /= g.CB;
-    const int64_t ki = kk % g.S; kk /= g.S;
-    const int64_t kj = kk % g.R;
-    const int64_t cb = kk / g.R;
-    Wm[i] = w[((k * g.C + cb * g.CB + c2) * g.R + kj) * g.S + ki];
-  }
+  if (g.K * g.KP <= 0x7FFFFFFF && g.K * g.C * g.R * g.S <= 0x7FFFFFFF && step <= 0x7FFFFFFF)   // uniform
+    pack_w_fp_body_t<uint32_t>(w, Wm, g, first, step);
+  else
+    pack_w_fp_body_t<int64_t>(w, Wm, g, first, step);
 }
 __global__ __launch_bounds__(NT) void pack_w_fp(const float *__restrict__ w, float *__restrict__ Wm, Geo g) {
   pack_w_fp_body(w, Wm, g, gtid(), gstride());
 }
 
 // gw[k][c][kj][ki] = Gw[k][(cb, kj, ki, c2)]
-__global__ __launch_bounds__(NT) void unpack_gw(const float *__restrict__ Gm, float *__restrict__ gw, Geo g) {
-  const int64_t crs = g.C * g.R * g.S, total = g.K * crs;
-  for (int64_t i = gtid(); i < total; i += gstride()) {
-    const int64_t k = i / crs;
-    int64_t kk = i % crs;
-    const int64_t c2 = kk % g.CB; kk /= g.CB;
-    const int64_t ki = kk % g.S; kk /= g.S;
-    const int64_t kj = kk % g.R;
-    const int64_t cb = kk / g.R;
-    gw[((k * g.C + cb * g.CB + c2) * g.R + kj) * g.S + ki] = Gm[i];
+template <class I>
+__device__ __forceinline__ void unpack_gw_t(const float *__restrict__ Gm, float *__restrict__ gw, const Geo &g) {
+  const I C = (I)g.C, R = (I)g.R, S = (I)g.S, CB = (I)g.CB;
+  const I crs = C * R * S, total = (I)g.K * crs;
+  for (I i = (I)gtid(); i < total; i += (I)gstride()) {
+    const I k = i / crs;
+    I kk = i - k * crs;
+    const I c2 = kk % CB; kk /= CB;
+    const I ki = kk % S; kk /= S;
+    const I kj = kk % R;
+    const I cb = kk / R;
+    gw[((k * C + cb * CB + c2) * R + kj) * S + ki] = Gm[i];
   }
+}
+__global__ __launch_bounds__(NT) void unpack_gw(const float *__restrict__ Gm, float *__restrict__ gw, Geo g) {
+  if (g.K * g.C * g.R * g.S <= 0x7FFFFFFF) unpack_gw_t<uint32_t>(Gm, gw, g);   // uniform
+  else unpack_gw_t<int64_t>(Gm, gw, g);
 }
 
 // Wbp[c][(ob, tj, ti, o2)] = w[ob*KB + o2][c][R-1-tj][ti]      (oj ascending = kj descending)
+template <class I>
+__device__ __forceinline__ void pack_w_bp_body_t(const float *__restrict__ w, float *__restrict__ Wm, const Geo &g,
+                                                 int64_t first, int64_t step) {
+  const I C = (I)g.C, R = (I)g.R, S = (I)g.S, KB = (I)g.KB;
+  const I krs = (I)g.K * R * S, total = C * krs;
+  for (I i = (I)first; i < total; i += (I)step) {
+    const I c = i / krs;
+    I kk = i - c * krs;
+    const I o2 = kk % KB; kk /= KB;
+    const I ti = kk % S; kk /= S;
+    const I tj = kk % R;
+    const I ob = kk / R;
+    Wm[i] = w[(((ob * KB + o2) * C + c) * R + (R - 1 - tj)) * S + ti];
+  }
+}
 __device__ __forceinline__ void pack_w_bp_body(const float *__restrict__ w, float *__restrict__ Wm, const Geo &g,
                                                int64_t first, int64_t step) {
-  const int64_t krs = g.K * g.R * g.S, total = g.C * krs;
-  for (int64_t i = first; i < total; i += step) {
-    const int64_t c = i / krs;
-    int64_t kk = i % krs;
-    const int64_t o2 = kk % g.KB; kk /= g.KB;
-    const int64_t ti = kk % g.S; kk /= g.S;
-    const int64_t tj = kk % g.R;
-    const int64_t ob = kk / g.R;
-    Wm[i] = w[(((ob * g.KB + o2) * g.C + c) * g.R + (g.R - 1 - tj)) * g.S + ti];
-  }
+  if (g.K * g.C * g.R * g.S <= 0x7FFFFFFF && step <= 0x7FFFFFFF) pack_w_bp_body_t<uint32_t>(w, Wm, g, first, step);   // uniform
+  else pack_w_bp_body_t<int64_t>(w, Wm, g, first, step);
 }
 __global__ __launch_bounds__(NT) void pack_w_bp(const float *__restrict__ w, float *__restrict__ Wm, Geo g) {
   pack_w_bp_body(w, Wm, g, gtid(), gstride());
@@ -207,37 +231,43 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
 // one 196-byte row at a time (C512 7 x 7 at batch 32: 147 456 rows, 92 us for 29 MB -- 40 % of that layer's weight
 // update).  Here a row gets 1 << LG lanes (the smallest power of two covering its pitch, up to 128) and a block takes
 // NT >> LG consecutive rows per trip; the row's tap is decoded per thread (three 32-bit divisions per row, not per pixel).
-template <int LG>
+template <int LG, int RB>   // RB consecutive rows (channels of one tap, as in cols_fp) per lane group
 __global__ __launch_bounds__(NT) void cols_fp_short(const float *__restrict__ x, float *__restrict__ cols, Geo g,
                                                     int64_t nrows, int rows_per_img, int pitch) {
-  constexpr int LPR = 1 << LG, RPB = NT >> LG;
+  constexpr int LPR = 1 << LG, RPB = (NT >> LG) * RB;
   const int P = (int)(g.OH * g.OW), OW = (int)g.OW, H = (int)g.H, W = (int)g.W, st = (int)g.stride;
   const int crs = (int)(g.C * g.R * g.S);
-  const int64_t HW = (int64_t)H * W;
-  const int lane = (int)threadIdx.x & (LPR - 1), rl = (int)threadIdx.x >> LG;
+  const int HW = H * W;
+  const int lane = (int)threadIdx.x & (LPR - 1), rl = ((int)threadIdx.x >> LG) * RB;
   for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < nrows; row0 += (int64_t)gridDim.x * RPB) {
     int64_t n = row0 / rows_per_img;                   // uniform over the block
     int kk = (int)(row0 - n * rows_per_img) + rl;
     while (kk >= rows_per_img) { kk -= rows_per_img; n++; }
     const int64_t row = row0 + rl;
-    if (row >= nrows) continue;
+    if (row >= nrows) continue;                        // (RB > 1: nrows is a multiple of RB)
     float *dst = cols + row * pitch;
-    const bool real = kk < crs;                        // else: a zero row that pads the chain to whole k tiles
+    const bool real = kk < crs;                        // else: zero rows that pad the chain to whole k tiles
     int k2 = real ? kk : 0;
     const int c2 = k2 % (int)g.CB; k2 /= (int)g.CB;
     const int ki = k2 % (int)g.S; k2 /= (int)g.S;
     const int kj = k2 % (int)g.R;
     const int cb = k2 / (int)g.R;
-    const float *src = x + (n * g.C + cb * g.CB + c2) * HW;
+    const float *src = x + (n * g.C + cb * g.CB + c2) * (int64_t)HW;
     const int y0 = kj - (int)g.pad, x0 = ki - (int)g.pad;
     for (int p = lane; p < pitch; p += LPR) {
-      float v = 0.f;
+      float v[RB];
+#pragma unroll
+      for (int u = 0; u < RB; u++) v[u] = 0.f;
       if (real && p < P) {
         const int oj = p / OW, oi = p - oj * OW;
         const int y = oj * st + y0, xx = oi * st + x0;
-        if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = src[y * W + xx];
+        if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) {
+#pragma unroll
+          for (int u = 0; u < RB; u++) v[u] = src[u * HW + y * W + xx];
+        }
       }
-      dst[p] = v;
+#pragma unroll
+      for (int u = 0; u < RB; u++) dst[(int64_t)u * pitch + p] = v[u];
     }
   }
 }
@@ -328,20 +358,26 @@ struct PhaseSet {
 };
 
 // Wph[c][(ob, aj, ai, o2)] = w[ob*KB + o2][c][kj][ki], kj = kj0 + (nj - 1 - aj) * st (descending), ki = ki0 + ai * st
+template <class I>
+__device__ __forceinline__ void pack_w_bp_phase_body_t(const float *__restrict__ w, float *__restrict__ Wm, const Geo &g,
+                                                       const Phase &ph, int64_t first, int64_t step) {
+  const I C = (I)g.C, R = (I)g.R, S = (I)g.S, KB = (I)g.KB, nj = (I)ph.nj, ni = (I)ph.ni, st = (I)g.stride;
+  const I krs = (I)g.K * nj * ni, total = C * krs;
+  for (I i = (I)first; i < total; i += (I)step) {
+    const I c = i / krs;
+    I kk = i - c * krs;
+    const I o2 = kk % KB; kk /= KB;
+    const I ai = kk % ni; kk /= ni;
+    const I aj = kk % nj;
+    const I ob = kk / nj;
+    const I kj = (I)ph.kj0 + (nj - 1 - aj) * st, ki = (I)ph.ki0 + ai * st;
+    Wm[i] = w[(((ob * KB + o2) * C + c) * R + kj) * S + ki];
+  }
+}
 __device__ __forceinline__ void pack_w_bp_phase_body(const float *__restrict__ w, float *__restrict__ Wm, const Geo &g,
                                                      const Phase &ph, int64_t first, int64_t step) {
-  const int64_t krs = g.K * ph.nj * ph.ni, total = g.C * krs;
-  const int st = (int)g.stride;
-  for (int64_t i = first; i < total; i += step) {
-    const int64_t c = i / krs;
-    int64_t kk = i % krs;
-    const int64_t o2 = kk % g.KB; kk /= g.KB;
-    const int64_t ai = kk % ph.ni; kk /= ph.ni;
-    const int64_t aj = kk % ph.nj;
-    const int64_t ob = kk / ph.nj;
-    const int64_t kj = ph.kj0 + (ph.nj - 1 - aj) * st, ki = ph.ki0 + ai * st;
-    Wm[i] = w[(((ob * g.KB + o2) * g.C + c) * g.R + kj) * g.S + ki];
-  }
+  if (g.K * g.C * g.R * g.S <= 0x7FFFFFFF && step <= 0x7FFFFFFF) pack_w_bp_phase_body_t<uint32_t>(w, Wm, g, ph, first, step);
+  else pack_w_bp_phase_body_t<int64_t>(w, Wm, g, ph, first, step);
 }
 
 __global__ __launch_bounds__(NT) void pack_w_bp_phase(const float *__restrict__ w, float *__restrict__ Wm_, Geo g, PhaseSet ps) {
@@ -723,12 +759,17 @@ void launch_cols_fp(const float *x, float *cols, const Geo &g, int64_t nrows, in
   if (!v4 && pitch <= 128) {
     int lg = 3;
     while ((1 << lg) < pitch) lg++;
-    const int64_t rpb = NT >> lg;
+    // four channel-consecutive rows per lane group where the channel block and the rows per image allow (a group's
+    // rows then share their tap and never straddle an image or the zero rows)
+    const bool rb4s = g.CB % 4 == 0 && rows_per_img % 4 == 0 && (g.C * g.R * g.S) % 4 == 0 && nrows % 4 == 0;
+    const int64_t rpb = (NT >> lg) * (rb4s ? 4 : 1);
     int64_t blocks = (nrows + rpb - 1) / rpb;
     if (blocks > 1048576) blocks = 1048576;
     if (blocks < 1) blocks = 1;
-    cols_fp_fn fn = lg == 3 ? cols_fp_short<3> : lg == 4 ? cols_fp_short<4> : lg == 5 ? cols_fp_short<5>
-                  : lg == 6 ? cols_fp_short<6> : cols_fp_short<7>;
+    cols_fp_fn fn = rb4s ? (lg == 3 ? cols_fp_short<3, 4> : lg == 4 ? cols_fp_short<4, 4> : lg == 5 ? cols_fp_short<5, 4>
+                            : lg == 6 ? cols_fp_short<6, 4> : cols_fp_short<7, 4>)
+                         : (lg == 3 ? cols_fp_short<3, 1> : lg == 4 ? cols_fp_short<4, 1> : lg == 5 ? cols_fp_short<5, 1>
+                            : lg == 6 ? cols_fp_short<6, 1> : cols_fp_short<7, 1>);
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(NT), 0, s, x, cols, g, nrows, (int)rows_per_img, (int)pitch);
     return;
   }
