@@ -386,16 +386,23 @@ __global__ __launch_bounds__(NT) void pack_w_bp_phase(const float *__restrict__ 
 
 // colsp[n][(ob, aj, ai, o2)][(yh, xh)] = gout[n][ob*KB + o2][yh + dj][xh + di] (0 outside), rows of ph.pitch floats
 // with a +0 tail.  One gathered row per blockIdx.y, threads along the phase's pixels.
-template <int RB>   // rows per block trip: RB consecutive output channels o2 of one tap (see cols_fp); needs KB % RB == 0
+// SHORT: rows of fewer than NT vectors (a 14 x 14 / 7 x 7 phase: pitch 256 / 64) get a lane group of 1 << lg lanes and a
+// block takes NT >> lg row groups per trip (the row's tap is then decoded per thread) -- one 256-thread block per
+// 64-float row left 240 lanes idle: 53 us for the C512 14 x 14 stride-2 layer's gather.
+template <int RB, bool SHORT>   // RB consecutive output channels o2 of one tap per lane group (see cols_fp); needs KB % RB == 0
 __global__ __launch_bounds__(NT) void cols_bp_phase(const float *__restrict__ go, float *__restrict__ cols_, Geo g, PhaseSet ps,
-                                                    int64_t nimg) {
+                                                    int64_t nimg, int lg) {
   const Phase ph = ps.ph[blockIdx.z];   // uniform: scalar loads from the kernel arguments
   float *cols = cols_ + ps.goff[blockIdx.z];
   const int OH = (int)g.OH, OW = (int)g.OW, st = (int)g.stride, Wh = ph.Wh, HWp = ph.Hh * ph.Wh;
   const int krs = (int)g.K * ph.nj * ph.ni;
   const int64_t nrows = nimg * krs;
   const int64_t plane = (int64_t)OH * OW;
-  for (int64_t row = (int64_t)blockIdx.y * RB; row < nrows; row += (int64_t)gridDim.y * RB) {
+  const int lpr = SHORT ? 1 << lg : NT;                                  // lanes per row group
+  const int lane = SHORT ? (int)threadIdx.x & (lpr - 1) : (int)threadIdx.x;
+  const int64_t rl = SHORT ? (int64_t)(threadIdx.x >> lg) : 0;           // row group of this thread within the block trip
+  const int64_t gpb = SHORT ? NT >> lg : 1;                              // row groups per block trip
+  for (int64_t row = ((int64_t)blockIdx.y * gpb + rl) * RB; row < nrows; row += (int64_t)gridDim.y * gpb * RB) {
     int kk = (int)(row % krs);
     const int64_t n = row / krs;
     const int o2 = kk % (int)g.KB; kk /= (int)g.KB;
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(NT) void cols_bp_phase(const float *__restrict__ go
     float *dst = cols + row * ph.pitch;
     // four pixels per lane and one 16-byte store (the pitch is a multiple of 64); four pixels of one plane row that all
     // exist come from one 4-byte-aligned 16-byte load
-    for (int pix = (blockIdx.x * NT + threadIdx.x) * 4; pix < ph.pitch; pix += gridDim.x * NT * 4) {
+    for (int pix = ((int)blockIdx.x * lpr + lane) * 4; pix < ph.pitch; pix += (int)gridDim.x * lpr * 4) {
       f32x4 o[RB];
 #pragma unroll
       for (int u = 0; u < RB; u++) o[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1096,9 +1103,15 @@ int fpemu_conv2d_bp_f32(float *gin, const float *gout, const float *w, int64_t N
       PhaseSet pc = ps;
       for (int q = 0; q < ps.count; q++) pc.goff[q] = ps.goff[q] * nb;
       if (ps.count > 0) {
-        dim3 gg = gather_grid(pitch_max / 4, nb * rows_max / (rb4 ? 4 : 1));
+        const int64_t vecs = pitch_max / 4, groups = nb * rows_max / (rb4 ? 4 : 1);
+        int lg = 4;   // lanes per row group: the smallest power of two covering the longest phase row's vectors
+        while ((1 << lg) < vecs && lg < 8) lg++;
+        const bool shortrows = lg < 8;
+        dim3 gg = shortrows ? gather_grid(vecs, (groups + (NT >> lg) - 1) / (NT >> lg)) : gather_grid(vecs, groups);
         gg.z = (unsigned)ps.count;
-        hipLaunchKernelGGL(rb4 ? cols_bp_phase<4> : cols_bp_phase<1>, gg, dim3(NT), 0, s, gout + n0 * K * P, gath, g, pc, nb);
+        void (*gk)(const float *, float *, Geo, PhaseSet, int64_t, int) =
+            shortrows ? (rb4 ? cols_bp_phase<4, true> : cols_bp_phase<1, true>) : (rb4 ? cols_bp_phase<4, false> : cols_bp_phase<1, false>);
+        hipLaunchKernelGGL(gk, gg, dim3(NT), 0, s, gout + n0 * K * P, gath, g, pc, nb, lg);
         CHECK_LAUNCH(who);
       }
       PhaseTable tb;
