@@ -147,19 +147,26 @@ typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 // they share every index and bounds computation and their loads are issued together -- a block that gathers one short
 // row lives one memory round trip per few KiB (measured on the strided layers: 57 us for 122 MB with RB = 1).  RB = 4
 // needs the channel block and the rows per image to be multiples of 4 (checked on the host).
-template <bool vec4, int ST, int RB>
+// SHORT (vec4 only): rows of fewer than NT vectors (14 x 14 outputs: 49) get a lane group of 1 << lg lanes and a block
+// takes NT >> lg row groups per trip, as cols_bp_phase.
+template <bool vec4, int ST, int RB, bool SHORT = false>
 __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float *__restrict__ cols, Geo g,
-                                              int64_t nrows, int rows_per_img, int pitch) {
+                                              int64_t nrows, int rows_per_img, int pitch, int lg) {
   // pitch: floats per gathered row, >= OH*OW (weight update: OH*OW padded to whole k tiles; the tail is +0)
   const int P = (int)(g.OH * g.OW), OW = (int)g.OW, H = (int)g.H, W = (int)g.W, st = (int)g.stride;
   const int crs = (int)(g.C * g.R * g.S);
   const int64_t HW = (int64_t)H * W;
-  for (int64_t row = (int64_t)blockIdx.y * RB; row < nrows; row += (int64_t)gridDim.y * RB) {
+  const int lpr = SHORT ? 1 << lg : NT;                                  // lanes per row group
+  const int lane = SHORT ? (int)threadIdx.x & (lpr - 1) : (int)threadIdx.x;
+  const int64_t rl = SHORT ? (int64_t)(threadIdx.x >> lg) : 0;
+  const int64_t gpb = SHORT ? NT >> lg : 1;                              // row groups per block trip
+  const int t0 = (int)blockIdx.x * lpr + lane, tstep = (int)gridDim.x * lpr;
+  for (int64_t row = ((int64_t)blockIdx.y * gpb + rl) * RB; row < nrows; row += (int64_t)gridDim.y * gpb * RB) {
     int kk = (int)(row % rows_per_img);
     const int64_t n = row / rows_per_img;
     float *dst = cols + row * pitch;
     if (kk >= crs) {  // the zero rows that pad the chain to whole k tiles (forward: rows_per_img = KP)
-      for (int p = blockIdx.x * NT + threadIdx.x; p < pitch; p += gridDim.x * NT)
+      for (int p = t0; p < pitch; p += tstep)
 #pragma unroll
         for (int u = 0; u < RB; u++) dst[(int64_t)u * pitch + p] = 0.f;
       continue;
@@ -169,12 +176,12 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
     const int kj = kk % (int)g.R;
     const int cb = kk / (int)g.R;
     const float *src = x + (n * g.C + cb * g.CB + c2) * HW;   // rows u = 0 .. RB-1: planes c2 + u
-    for (int p = P + blockIdx.x * NT + threadIdx.x; p < pitch; p += gridDim.x * NT)
+    for (int p = P + t0; p < pitch; p += tstep)
 #pragma unroll
       for (int u = 0; u < RB; u++) dst[(int64_t)u * pitch + p] = 0.f;
     const int y0 = kj - (int)g.pad, x0 = ki - (int)g.pad;
     if constexpr (vec4) {  // four pixels per lane, one 16-byte store (rows are whole vectors and 16-byte aligned)
-      for (int p = (blockIdx.x * NT + threadIdx.x) * 4; p < P; p += gridDim.x * NT * 4) {
+      for (int p = t0 * 4; p < P; p += tstep * 4) {
         f32x4 o[RB];
         int oj = p / OW, oi = p - oj * OW;
         bool done = false;
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
       }
       continue;
     }
-    for (int p = blockIdx.x * NT + threadIdx.x; p < P; p += gridDim.x * NT) {
+    for (int p = t0; p < P; p += tstep) {
       const int oj = p / OW, oi = p - oj * OW;
       const int y = oj * st + y0, xx = oi * st + x0;
       const bool in = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(NT) void cols_fp(const float *__restrict__ x, float
 // NT >> LG consecutive rows per trip; the row's tap is decoded per thread (three 32-bit divisions per row, not per pixel).
 template <int LG, int RB>   // RB consecutive rows (channels of one tap, as in cols_fp) per lane group
 __global__ __launch_bounds__(NT) void cols_fp_short(const float *__restrict__ x, float *__restrict__ cols, Geo g,
-                                                    int64_t nrows, int rows_per_img, int pitch) {
+                                                    int64_t nrows, int rows_per_img, int pitch, int) {
   constexpr int LPR = 1 << LG, RPB = (NT >> LG) * RB;
   const int P = (int)(g.OH * g.OW), OW = (int)g.OW, H = (int)g.H, W = (int)g.W, st = (int)g.stride;
   const int crs = (int)(g.C * g.R * g.S);
@@ -272,9 +279,13 @@ __global__ __launch_bounds__(NT) void cols_fp_short(const float *__restrict__ x,
   }
 }
 
-typedef void (*cols_fp_fn)(const float *, float *, Geo, int64_t, int, int);
-cols_fp_fn pick_cols_fp(bool vec4, int64_t stride, bool rb4) {
+typedef void (*cols_fp_fn)(const float *, float *, Geo, int64_t, int, int, int);
+cols_fp_fn pick_cols_fp(bool vec4, int64_t stride, bool rb4, bool shortrows) {
   if (!vec4) return cols_fp<false, 0, 1>;
+  if (shortrows) {
+    if (rb4) return stride == 1 ? cols_fp<true, 1, 4, true> : stride == 2 ? cols_fp<true, 2, 4, true> : cols_fp<true, 0, 4, true>;
+    return stride == 1 ? cols_fp<true, 1, 1, true> : stride == 2 ? cols_fp<true, 2, 1, true> : cols_fp<true, 0, 1, true>;
+  }
   if (rb4) return stride == 1 ? cols_fp<true, 1, 4> : stride == 2 ? cols_fp<true, 2, 4> : cols_fp<true, 0, 4>;
   return stride == 1 ? cols_fp<true, 1, 1> : stride == 2 ? cols_fp<true, 2, 1> : cols_fp<true, 0, 1>;
 }
@@ -777,11 +788,17 @@ void launch_cols_fp(const float *x, float *cols, const Geo &g, int64_t nrows, in
                             : lg == 6 ? cols_fp_short<6, 4> : cols_fp_short<7, 4>)
                          : (lg == 3 ? cols_fp_short<3, 1> : lg == 4 ? cols_fp_short<4, 1> : lg == 5 ? cols_fp_short<5, 1>
                             : lg == 6 ? cols_fp_short<6, 1> : cols_fp_short<7, 1>);
-    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(NT), 0, s, x, cols, g, nrows, (int)rows_per_img, (int)pitch);
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(NT), 0, s, x, cols, g, nrows, (int)rows_per_img, (int)pitch, 0);
     return;
   }
-  hipLaunchKernelGGL(pick_cols_fp(v4, stride, rb4), gather_grid(P, nrows / (rb4 ? 4 : 1)), dim3(NT), 0, s, x, cols, g, nrows,
-                     (int)rows_per_img, (int)pitch);
+  // whole vectors but fewer than a block's worth per row (the tail beyond P is written by the same lanes)
+  int lg = 4;
+  const int64_t vecs = (pitch + 3) / 4, groups = nrows / (rb4 ? 4 : 1);
+  while ((1 << lg) < vecs && lg < 8) lg++;
+  const bool shortrows = v4 && lg < 8;
+  const dim3 grid = shortrows ? gather_grid(P, (groups + (NT >> lg) - 1) / (NT >> lg)) : gather_grid(P, groups);
+  hipLaunchKernelGGL(pick_cols_fp(v4, stride, rb4, shortrows), grid, dim3(NT), 0, s, x, cols, g, nrows, (int)rows_per_img,
+                     (int)pitch, lg);
 }
 
 int fail(const char *who, int code, const char *what) {
