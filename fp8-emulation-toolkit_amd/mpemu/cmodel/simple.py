@@ -163,18 +163,24 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     return res
 
 
-def _grads(grad_output, mat1, mat2, alpha, a_trans, b_trans):
-    """d/d(mat1), d/d(mat2) of alpha * op(mat1) @ op(mat2), each one cmodel GEMM (simple.py:155-178)."""
-    g1, g2 = torch.zeros_like(mat1), torch.zeros_like(mat2)
+def _grads(grad_output, mat1, mat2, alpha, a_trans, b_trans, need1=True, need2=True):
+    """d/d(mat1), d/d(mat2) of alpha * op(mat1) @ op(mat2), each one cmodel GEMM (simple.py:155-178).  A gradient
+    autograd does not ask for (ctx.needs_input_grad: a frozen weight, an input that requires none) is not computed --
+    the reference computes both regardless and autograd drops the unused one."""
+    g1 = g2 = None
     go, o_trans = is_transposed(grad_output)
-    if a_trans:
-        _gemm(g1, mat2, go, alpha, b_trans, not o_trans)
-    else:
-        _gemm(g1, go, mat2, alpha, o_trans, not b_trans)
-    if b_trans:
-        _gemm(g2, go, mat1, alpha, not o_trans, a_trans)
-    else:
-        _gemm(g2, mat1, go, alpha, not a_trans, o_trans)
+    if need1:
+        g1 = torch.zeros_like(mat1)
+        if a_trans:
+            _gemm(g1, mat2, go, alpha, b_trans, not o_trans)
+        else:
+            _gemm(g1, go, mat2, alpha, o_trans, not b_trans)
+    if need2:
+        g2 = torch.zeros_like(mat2)
+        if b_trans:
+            _gemm(g2, go, mat1, alpha, not o_trans, a_trans)
+        else:
+            _gemm(g2, mat1, go, alpha, not a_trans, o_trans)
     return g1, g2
 
 
@@ -191,7 +197,8 @@ class SimpleAddmm(Function):
     @staticmethod
     def backward(ctx, grad_output):
         mat1, mat2 = ctx.saved_tensors
-        g1, g2 = _grads(grad_output, mat1, mat2, ctx.alpha, ctx.a_trans, ctx.b_trans)
+        g1, g2 = _grads(grad_output, mat1, mat2, ctx.alpha, ctx.a_trans, ctx.b_trans, ctx.needs_input_grad[2],
+                        ctx.needs_input_grad[3])
         return grad_output, grad_output, g1, g2, None, None, None, None
 
 
@@ -207,7 +214,8 @@ class SimpleMatmul(Function):
     @staticmethod
     def backward(ctx, grad_output):
         mat1, mat2 = ctx.saved_tensors
-        g1, g2 = _grads(grad_output, mat1, mat2, ctx.alpha, ctx.a_trans, ctx.b_trans)
+        g1, g2 = _grads(grad_output, mat1, mat2, ctx.alpha, ctx.a_trans, ctx.b_trans, ctx.needs_input_grad[1],
+                        ctx.needs_input_grad[2])
         return grad_output, g1, g2, None, None, None, None
 
 
@@ -225,8 +233,13 @@ class SimpleConv2dFunction(Function):
     def backward(ctx, grad_output):
         inputs, weights = ctx.saved_tensors
         grad_output = grad_output.contiguous()
-        grad_inp = torch.empty_like(inputs)
-        grad_wts = torch.empty_like(weights)
-        _hip.conv2d_bp_(grad_inp, grad_output, weights, ctx.stride[0], ctx.padding[0], _variant)
-        _hip.conv2d_wu_(grad_wts, grad_output, inputs, ctx.stride[0], ctx.padding[0], _variant)
+        grad_inp = grad_wts = None
+        # a gradient autograd does not ask for is not computed (a network's first convolution: the images need none --
+        # 0.36 ms of backward-data at batch 32; the reference computes both regardless and autograd drops the unused one)
+        if ctx.needs_input_grad[1]:
+            grad_inp = torch.empty_like(inputs)
+            _hip.conv2d_bp_(grad_inp, grad_output, weights, ctx.stride[0], ctx.padding[0], _variant)
+        if ctx.needs_input_grad[2]:
+            grad_wts = torch.empty_like(weights)
+            _hip.conv2d_wu_(grad_wts, grad_output, inputs, ctx.stride[0], ctx.padding[0], _variant)
         return grad_output, grad_inp, grad_wts, None, None, None, None, None, None

@@ -210,6 +210,15 @@ def test_simple_conv2d_module_api(hip):
     assert_bits_equal(tw.grad.cpu().numpy(), orc.conv2d_wu(go, x, (3, 3), 2, 1, True), "grad weight")
     ref = torch.nn.functional.conv2d(_t(x), _t(w), tb, stride=2, padding=1)
     assert torch.allclose(y.detach(), ref, rtol=1e-4, atol=1e-4)
+    # only the gradients autograd asks for are computed: images that need none (a first layer), a frozen weight
+    ux, uw = _t(x), _t(w).requires_grad_(True)
+    simple.conv2d(ux, uw, tb, stride=(2, 2), padding=(1, 1), dilation=(1, 1), groups=1).backward(_t(go))
+    assert ux.grad is None
+    assert_bits_equal(uw.grad.cpu().numpy(), orc.conv2d_wu(go, x, (3, 3), 2, 1, True), "grad weight, input needs none")
+    vx, vw = _t(x).requires_grad_(True), _t(w)
+    simple.conv2d(vx, vw, tb, stride=(2, 2), padding=(1, 1), dilation=(1, 1), groups=1).backward(_t(go))
+    assert vw.grad is None
+    assert_bits_equal(vx.grad.cpu().numpy(), orc.conv2d_bp(go, w, (10, 10), 2, 1, True), "grad input, frozen weight")
     for bad in (dict(dilation=(2, 2)), dict(padding=(1, 0)), dict(groups=2), dict(stride=(1, 2))):
         with pytest.raises(ValueError):
             simple.conv2d(tx, tw, tb, **bad)

@@ -139,6 +139,15 @@ def test_simple_module_api(hip):
     y.backward(_t(gout))
     assert_bits_equal(ta.grad.cpu().numpy(), orc.gemm(gout, b, b_trans=True, fused=True), "grad a")
     assert_bits_equal(tb.grad.cpu().numpy(), orc.gemm(a, gout, a_trans=True, fused=True), "grad b")
+    # only the gradients autograd asks for are computed (a frozen weight; activations that need none)
+    ua, ub = _t(a).requires_grad_(True), _t(b)
+    simple.mm(ua, ub).backward(_t(gout))
+    assert ub.grad is None
+    assert_bits_equal(ua.grad.cpu().numpy(), orc.gemm(gout, b, b_trans=True, fused=True), "grad a, frozen b")
+    va, vb = _t(a), _t(b).requires_grad_(True)
+    simple.addmm(_t(bias), va, vb, beta=1.0, alpha=1.0).backward(_t(gout))
+    assert va.grad is None
+    assert_bits_equal(vb.grad.cpu().numpy(), orc.gemm(a, gout, a_trans=True, fused=True), "grad b, a needs none")
     simple.set_accumulation("separate")
     try:
         assert_bits_equal(simple.mm(_t(a), _t(b)).cpu().numpy(), orc.gemm(a, b, fused=False), "separate")
