@@ -20,6 +20,8 @@ all-reduce, one copy back.  That is what torch's own gloo device-tensor path doe
 pinned bounce buffer per call plus a stream synchronise on a gloo worker thread), minus the
 per-call pinned allocation and the second thread; see DESIGN.md section 4 for what was measured.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -28,6 +30,13 @@ from .pytquant.hip import _binding as _hip
 # Shards start on a multiple of this many elements: keeps every shard 16-byte aligned for fp32 and
 # 16-bit storage and on a noise-superblock boundary of the stochastic modes (2048 = 8 x 64 x 4).
 SHARD_ALIGN = 2048
+# A group of one rank has nothing to reduce and all_reduce_max_words returns at once.  tests/test_gpu_sharded.py
+# clears this to send the nccl branch (torch -> RCCL all-reduce(MAX) of int32 words, the device-side offset guard)
+# through a one-rank RCCL communicator: the only way to execute that branch on a box with a single GPU.
+_SINGLE_RANK_SHORTCUT = True
+# MPEMU_CHECK_OFFSETS=1: the nccl branch verifies the stochastic call offset synchronously at every call (a host
+# sync per call; the default is the device-side guard that later calls poll).
+_CHECK_OFFSETS = os.environ.get("MPEMU_CHECK_OFFSETS", "0") not in ("", "0")
 
 
 def group_backend(group=None):
@@ -114,7 +123,7 @@ def all_reduce_max_words(words, group=None, check_equal=None):
     words and compared on the device into an error word (_OffsetGuard) that later calls poll without blocking;
     MPEMU_CHECK_OFFSETS=1 makes every call check synchronously.  Raises RuntimeError when ranks disagree."""
     backend = group_backend(group)
-    if backend is None or dist.get_world_size(group) == 1:
+    if backend is None or (_SINGLE_RANK_SHORTCUT and dist.get_world_size(group) == 1):
         return words
     verify = check_equal is not None
     if verify:
@@ -194,6 +203,10 @@ class ShardedCaster(object):
     def _world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def _collective(self):
+        """Whether the words go through all_reduce_max_words (more than one rank; or the tests' one-rank drive)."""
+        return self._world() > 1 or (not _SINGLE_RANK_SHORTCUT and group_backend(self.group) is not None)
+
     def cast(self, shard, mode, scale=1.0, elem_base=0, inplace=False, seed=None, offset=None):
         """Unscaled / given-scale cast of the shard: no communication."""
         fmt, rmode = self.ops.parse_mode(mode)
@@ -224,7 +237,7 @@ class ShardedCaster(object):
             words = torch.zeros(len(shards), dtype=torch.int32, device=dev)
         for i, s in enumerate(shards):
             self.ops.amax_(s, words[i:i + 1])
-        if self._world() > 1:
+        if self._collective():
             all_reduce_max_words(words, self.group)
         return words
 
@@ -244,7 +257,7 @@ class ShardedCaster(object):
         if words is None:
             words = torch.empty(len(shards), dtype=torch.int32, device=shards[0].device)
         self.ops.amax_multi_(shards, words)
-        if self._world() > 1:
+        if self._collective():
             all_reduce_max_words(words, self.group)
         outs = shards if inplace else [torch.empty_like(t) for t in shards]
         self.ops.cast_multi_scaled_(shards, fmt, rmode, words, flt_max, dsts=outs, clamp=clamp)
@@ -279,7 +292,7 @@ class ShardedCaster(object):
                     self.ops.amax_(piece[r * nc:(r + 1) * nc], words[r0 + r:r0 + r + 1])
             else:
                 self.ops.amax_rows_(piece, nr, words[r0:r0 + nr])
-        if self._world() > 1:
+        if self._collective():
             all_reduce_max_words(words, self.group, check_equal=offset if rmode == self.ops.STOCHASTIC else None)
         for lo, nr, nc, r0, c0 in segs:
             src, dst = flat[lo:lo + nr * nc], out[lo:lo + nr * nc]

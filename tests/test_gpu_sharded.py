@@ -171,3 +171,75 @@ def test_rccl_one_rank_per_gpu(tmp_path):
     mp.spawn(_qutils_worker, args=(world, _free_port(), n, str(tmp_path), "nccl"), nprocs=world, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True) for r in range(world)]
     _check_qutils_parts(parts, n)
+
+
+def _one_rank_rccl_worker(rank, world, port, n, outdir):
+    """A one-rank RCCL communicator on the box's GPU with the single-rank shortcut off: every collective of the
+    product's nccl branch really goes through torch -> RCCL (all-reduce(MAX) of int32 words on the device, in stream
+    order), and the device-side offset guard runs with its pinned word and event polling."""
+    for p in (os.path.join(ROOT, "fp8-emulation-toolkit_amd"), os.path.join(ROOT, "oracle"),
+              os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from mpemu import qutils, sharded
+    from mpemu.pytquant.hip import _binding as hip
+
+    sharded._SINGLE_RANK_SHORTCUT = False
+    assert sharded.group_backend() == "nccl"
+    x = _data(n)
+    t = torch.from_numpy(x).to(dev)
+    res = {}
+    # plain words, back to back
+    w = torch.tensor([5, 0x45200000, 0], dtype=torch.int32, device=dev)
+    for _ in range(30):
+        sharded.all_reduce_max_words(w)
+    res["plain"] = w.cpu()
+    # the hooks' entry point under the group: per-tensor stochastic (offset guard), deterministic, per-channel rows
+    qutils.set_amax_process_group(dist.group.WORLD, elem_base=lambda tt: 0)
+    hip.set_rng_state((1234, 20))
+    cfg = qutils.TensorQuantConfig("e5m2", "stochastic", "per-tensor")
+    res["sr"] = qutils.quantize_tensor(t, cfg, None).cpu()                       # offset 20
+    for _ in range(12):                                                          # the guard's polls land
+        qutils.quantize_tensor(t, cfg, None)
+    res["rne"] = qutils.quantize_tensor(t, qutils.TensorQuantConfig("e4m3", "rne", "per-tensor"), None).cpu()
+    qutils.set_amax_process_group(None)
+    sharded.check_offsets()
+    sc = sharded.ShardedCaster()
+    res["q"] = sc.quantize_per_tensor(t, "E4M3_RNE", 448.0).cpu()
+    rows, cols = 100, n // 100
+    flat = t[:rows * cols].contiguous()
+    out, words = sc.quantize_rows_flat(flat, rows, cols, 0, "E4M3_STOCHASTIC", 448.0, seed=5, offset=40)
+    res["rows"] = out.cpu()
+    outs, _w = sc.quantize_per_tensor_multi([t.clone(), (t * 0.5)], "E4M3_RNE", 448.0)
+    res["multi0"], res["multi1"] = outs[0].cpu(), outs[1].cpu()
+    sharded.check_offsets()
+    torch.cuda.synchronize()
+    torch.save(res, os.path.join(outdir, "one.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_communicator_drives_the_nccl_branch(tmp_path):
+    n = 300000
+    mp.spawn(_one_rank_rccl_worker, args=(1, _free_port(), n, str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "one.pt"), weights_only=True)
+    x = _data(n)
+    assert res["plain"].tolist() == [5, 0x45200000, 0]
+    s5 = orc.scale_from_amax(orc.amax(x), 57344.0)
+    s4 = orc.scale_from_amax(orc.amax(x), 448.0)
+    assert_bits_equal(res["sr"].numpy(), orc.cast(x, "E5M2_STOCHASTIC", scale=s5, seed=1234, offset=20), "SR")
+    assert_bits_equal(res["rne"].numpy(), orc.cast(x, "E4M3_RNE", scale=s4), "RNE")
+    assert_bits_equal(res["q"].numpy(), orc.cast(x, "E4M3_RNE", scale=s4), "ShardedCaster")
+    assert_bits_equal(res["multi0"].numpy(), orc.cast(x, "E4M3_RNE", scale=s4), "multi 0")
+    h = (x * np.float32(0.5)).astype(np.float32)
+    assert_bits_equal(res["multi1"].numpy(), orc.cast(h, "E4M3_RNE", scale=orc.scale_from_amax(orc.amax(h), 448.0)),
+                      "multi 1")
+    rows, cols = 100, n // 100
+    got = res["rows"].numpy().reshape(rows, cols)
+    for r in (0, 1, 57, 99):
+        row = x[r * cols:(r + 1) * cols]
+        s = orc.scale_from_amax(orc.amax(row), 448.0)
+        assert_bits_equal(got[r], orc.cast(row, "E4M3_STOCHASTIC", scale=s, seed=5, offset=40 + r), "row %d" % r)

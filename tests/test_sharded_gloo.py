@@ -179,3 +179,55 @@ def test_all_reduce_max_words_back_to_back(tmp_path):
     for r in range(2):
         w = torch.load(os.path.join(str(tmp_path), "w%d.pt" % r), weights_only=True)
         assert w.tolist() == [11, 7, 0]
+
+
+def _device_branch_worker(rank, world, port, outdir):
+    """The nccl branch of all_reduce_max_words (words reduced where they live, the (o, -o) pair compared into the
+    guard's error word) driven over gloo with CPU tensors: group_backend is patched to answer "nccl"."""
+    for p in (os.path.join(ROOT, "fp8-emulation-toolkit_amd"),):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mpemu import sharded
+
+    sharded.group_backend = lambda group=None: "nccl"
+    res = {}
+    w = torch.tensor([rank * 10 + 1, 7 - rank], dtype=torch.int32)
+    sharded.all_reduce_max_words(w)                                   # no offset: plain reduce
+    res["plain"] = w.clone()
+    w = torch.tensor([rank + 3, 100 - rank, 5], dtype=torch.int32)
+    for o in range(20, 40):                                           # agreeing offsets, back to back: polled guard
+        sharded.all_reduce_max_words(w, check_equal=o)
+    sharded.check_offsets()
+    res["agree"] = w.clone()
+    w = torch.tensor([rank], dtype=torch.int32)
+    try:                                                              # skewed: the guard's word records it; a CPU
+        sharded.all_reduce_max_words(w, check_equal=50 + rank)        # guard reads the word at its next poll (this
+        sharded.check_offsets()                                       # call's), a GPU guard a few calls later or at
+        res["skew"] = ""                                              # the synchronous check
+    except RuntimeError as e:
+        res["skew"] = str(e)
+    res["skew_words"] = w.clone()
+    sharded.check_offsets()                                           # raising cleared the word
+    sharded._CHECK_OFFSETS = True                                     # MPEMU_CHECK_OFFSETS=1: raise at the call
+    try:
+        sharded.all_reduce_max_words(torch.tensor([1], dtype=torch.int32), check_equal=7 * rank)
+        res["sync"] = ""
+    except RuntimeError as e:
+        res["sync"] = str(e)
+    sharded.all_reduce_max_words(torch.tensor([1], dtype=torch.int32), check_equal=9)
+    torch.save(res, os.path.join(outdir, "d%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_device_side_branch_and_offset_guard_over_gloo(tmp_path):
+    mp.spawn(_device_branch_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(str(tmp_path), "d%d.pt" % r), weights_only=True)
+        assert res["plain"].tolist() == [11, 7]
+        assert res["agree"].tolist() == [4, 100, 5]
+        assert res["skew_words"].tolist() == [1]
+        assert "disagree on the stochastic call offset" in res["skew"]
+        assert "disagree on the stochastic call offset" in res["sync"]
