@@ -200,7 +200,11 @@ def main():
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # FPEMU_BENCH_REHEARSE=1 (under a launcher, --gpus 1): every collective of the N > 1 flow -- barriers, the timing
+    # reduction, the amax all-reduce, the checksum gather -- through a ONE-rank communicator of the chosen backend: the
+    # RCCL calls of the multi-GPU bench executed on a box with a single GPU (tools/gpu.sh check)
+    multi = world > 1 or (os.environ.get("FPEMU_BENCH_REHEARSE") == "1" and "WORLD_SIZE" in os.environ)
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -208,8 +212,11 @@ def main():
             dist.init_process_group(backend)
 
     from mpemu.pytquant.hip import _binding as hip
+    from mpemu import sharded
     from mpemu.sharded import all_reduce_max_words
 
+    if multi and world == 1:
+        sharded._SINGLE_RANK_SHORTCUT = False
     hip.lib()
     n = args.elems
     x = synth(n, dev, 1234 + rank)
@@ -221,12 +228,12 @@ def main():
         hip.cast_(x, y, fmt, rm, scale=1.0, seed=1, offset=0, elem_base=rank * n)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     def reduce_max_f64(v):
         """MAX of one Python float over the ranks (RCCL on the device; other backends on the host)."""
-        if world == 1:
+        if not multi:
             return v
         t = torch.tensor([v], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -234,7 +241,7 @@ def main():
 
     def gather_i64(vals):
         """Every rank's list of 64-bit integers, on every rank: [world][len(vals)]."""
-        if world == 1:
+        if not multi:
             return [list(vals)]
         t = torch.tensor(vals, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
         outs = [torch.empty_like(t) for _ in range(world)]
@@ -265,8 +272,9 @@ def main():
         step()
     ev1.record()
     torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
+    t1 = time.perf_counter()  # this rank's K steps are done; the closing barrier follows, the MAX over ranks is below
+    barrier()                 # (read after the barrier, an RCCL barrier's own launch + sync -- ~0.1-0.2 ms, rehearsed
+    #                            with one rank -- would be charged to the K steps: 3 % of a 20-step region)
     ms = reduce_max_f64((t1 - t0) * 1e3 / args.steps)
     value = world * n / (ms * 1e-3)
 
@@ -349,7 +357,7 @@ def main():
         def scaled_step():
             ws.zero_()
             hip.amax_(xf, ws)
-            if world > 1:
+            if multi:
                 all_reduce_max_words(ws)
             hip.cast_scaled_(xf, y, fmt, rm, ws, 448.0, clamp=True, seed=1, offset=0, elem_base=base)
 
@@ -363,7 +371,7 @@ def main():
         # the collective alone: all-reduce(MAX) of the one amax word, back to back (RCCL: two events on the stream
         # the all-reduce is enqueued on; host-staged backends: wall clock around the synchronising calls)
         collective_us = None
-        if world > 1:
+        if multi:
             cw = torch.zeros(1, dtype=torch.int32, device=dev)
             for _ in range(5):
                 all_reduce_max_words(cw)
@@ -380,12 +388,12 @@ def main():
         extras["scaled_per_tensor"] = {"ms_per_step": round(s_avg, 5),
                                        "GB/s_per_gpu": round(12 * n / (s_avg * 1e-3) / 1e9, 1),
                                        "elements/s_whole_job": round(world * n / (s_avg * 1e-3), 1),
-                                       "collective": "all_reduce(max) of 4 B" if world > 1 else "none",
+                                       "collective": "all_reduce(max) of 4 B" if multi else "none",
                                        "collective_us": collective_us,
                                        "timing": "two HIP events around 20 steps (amax + all-reduce + cast), max over ranks",
                                        "verified": verified["scaled_per_tensor"]}
 
-        if world == 1:
+        if not multi:
             # the local fused form (no collective): per-block maxima + cast, two launches
             def fused_step():
                 hip.quantize_per_tensor_(xf, y, fmt, rm, 448.0)
@@ -397,7 +405,7 @@ def main():
                                           "verified": verified["fused_per_tensor"]}
 
         # ---- N > 1: the N-GPU result is the 1-GPU result of the same global tensor ----------------
-        if world > 1:
+        if multi:
             sums = {}
             step()
             sums["unscaled"] = checksum64(y)
@@ -444,7 +452,7 @@ def main():
             def shard_step():
                 ws.zero_()
                 hip.amax_(xb, ws)
-                if world > 1:
+                if multi:
                     all_reduce_max_words(ws)
                 hip.cast_scaled_(xb, yb, fmt, rm, ws, 448.0, clamp=True, seed=1, offset=0, elem_base=rank * big)
 
@@ -461,7 +469,7 @@ def main():
             extras["shard_8GiB_scaled"] = {"ms_per_step": round(b_avg, 4),
                                            "GB/s_per_gpu": round(12 * big / (b_avg * 1e-3) / 1e9, 1),
                                            "tensor_GiB": 8 * world,
-                                           "collective": "all_reduce(max) of 4 B" if world > 1 else "none",
+                                           "collective": "all_reduce(max) of 4 B" if multi else "none",
                                            "verified": verified["shard_8GiB_scaled"]}
             del xb, yb
         except torch.cuda.OutOfMemoryError:
@@ -493,7 +501,7 @@ def main():
             extras["modes_verified"] = modes_ok
             verified["modes"] = all(modes_ok.values())
 
-        if rank == 0 and world == 1:
+        if rank == 0 and not multi:
             # per-channel rows kernel: 8 B/elem algorithmic (the row is held on chip between its
             # maximum and its cast: one read + one write)
             def rows_oracle(h, cols, clamp=True):
@@ -660,7 +668,7 @@ def main():
                 verified["conv_fp_3x3_c64_56"] = False
         del xf
 
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and not multi and not args.no_extras:
         sample = min(n, 1 << 28)
         hxs = x[:sample].cpu().numpy()
         orc.cast(hxs[: 1 << 24], args.mode)  # warm pass (threads, page tables)
@@ -706,7 +714,7 @@ def main():
             "scaled_step": extras.get("scaled_per_tensor"), "extras": extras,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()  # rank 0's extras run longer than the others': leave together
         dist.destroy_process_group()
 

@@ -50,6 +50,15 @@ import json
 d = json.loads(open("gpurun_out/bench_gloo2.log").read().strip().splitlines()[-1])
 print("gloo x2 (one GPU): n_gpus", d["n_gpus"], "checksums", d["extras"].get("sharded_checksums"), "all_verified", d["extras"].get("all_verified"))
 PY
+  # the N > 1 flow's RCCL calls through a ONE-rank communicator (the only RCCL run a 1-GPU box allows)
+  FPEMU_BENCH_REHEARSE=1 FPEMU_BENCH_WATCHDOG=240 timeout -k 10 300 python -u -m torch.distributed.run --nnodes=1 \
+    --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 \
+    > gpurun_out/bench_rccl1.log 2> gpurun_out/bench_rccl1.err || { tail -n 30 gpurun_out/bench_rccl1.err; exit 1; }
+  python3 - <<'PY'
+import json
+d = json.loads(open("gpurun_out/bench_rccl1.log").read().strip().splitlines()[-1])
+print("rccl x1 rehearsal: scaled_step", d["scaled_step"], "checksums", d["extras"].get("sharded_checksums"), "all_verified", d["extras"].get("all_verified"))
+PY
   ;;
 profile)    # bench.py under rocprofv3: kernel stats, then FETCH_SIZE and WRITE_SIZE in separate passes; GEMM kernel stats
   P=gpurun_out/prof
