@@ -219,8 +219,13 @@ def main():
         sharded._SINGLE_RANK_SHORTCUT = False
     hip.lib()
     n = args.elems
-    x = synth(n, dev, 1234 + rank)
-    y = torch.empty_like(x)
+    # Input and output are the two halves of ONE allocation (the output starts where the input ends): where the
+    # allocator happens to put two separate 1 GiB blocks moves the cast by about +-0.7 % (tools/offset_probe.py,
+    # profiles/r03_offset_probe.txt: 6.80-6.90 TB/s over eleven placements on one box), so the placement is fixed here
+    # instead of left to chance.  Both buffers stay caller-owned and distinct: the out-of-place workload as named.
+    xy = torch.empty(2 * n, dtype=torch.float32, device=dev)
+    x, y = xy[:n], xy[n:]
+    x.copy_(synth(n, dev, 1234 + rank))
     fmt, rm = hip.parse_mode(args.mode)
     stream = torch.cuda.current_stream(dev).cuda_stream
 

@@ -922,6 +922,15 @@ extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float 
                                        int64_t M, int64_t cblocks, int64_t R, int64_t S, int64_t plane, int64_t Wp,
                                        int64_t OH, int64_t OW, int reverse, uint32_t *amax, void *stream);
 extern "C" int fpemu_gemm_conv_tile_(int64_t M, int64_t nvalid, int64_t batch);
+extern "C" int fpemu_gemm_wu_implicit_ok_(const float *gout, int64_t K, int64_t crs, int64_t P, int64_t OW, int64_t kseg_a,
+                                          int variant);
+extern "C" int fpemu_gemm_wu_implicit_launch_(float *Gm, const float *gout, const float *xp, int64_t K, int64_t crs,
+                                              int64_t P, int64_t images, int64_t kseg_a, int64_t kseg_b, int start,
+                                              int64_t CB, int64_t R, int64_t S, int64_t plane, int64_t Wp, int64_t OW,
+                                              void *stream);
+#ifndef FPEMU_CONV_WU_IMPLICIT
+#define FPEMU_CONV_WU_IMPLICIT 1
+#endif
 
 namespace {
 
@@ -1224,7 +1233,30 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
     hipLaunchKernelGGL(fill_zero, dim3(blocks_for(K * crs)), dim3(NT), 0, s, Gm, K * crs);
     CHECK_LAUNCH(who);
   }
-  for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+  // Stride 1 on the small-tile chain kernels (ResNet-50's 56 x 56 and 28 x 28 layers): no gathered operand.  cols_fp
+  // writes R*S shifted copies of every plane (220 MiB for the 24.5 MiB input of the C64 56 x 56 layer, read back by the
+  // GEMM: 62 of that call's 446 us); the GEMM's loader waves read the same values from the planes themselves -- zero-padded
+  // once (pad_planes, as the implicit forward), or the input as it is when there is no padding (1 x 1 filters).
+  const int64_t Hp = H + 2 * pad, Wp = W + 2 * pad;
+  static const bool no_implicit = getenv("FPEMU_CONV_WU_GATHER") != nullptr;   // tuning aid (tools/conv_bench.py)
+  const bool implicit = FPEMU_CONV_WU_IMPLICIT && !no_implicit && stride == 1 && N > 0 && Pp == P &&
+                        (pad == 0 || C * Hp * Wp <= per) &&
+                        fpemu_gemm_wu_implicit_ok_(gout, K, crs, P, g.OW, K * P, variant);
+  for (int64_t n0 = 0; implicit && n0 < N; n0 += chunk) {
+    const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
+    const float *xp = in + n0 * C * H * W;
+    if (pad != 0) {
+      const unsigned pb = blocks_for((nb * C * Hp * Wp + 3) / 4);
+      hipLaunchKernelGGL(pad_planes<0>, dim3(pb), dim3(NT), 0, s, xp, cols, nb * C, (int)H, (int)W, (int)Hp, (int)Wp, (int)pad,
+                         (int)pad, pb, PackJob{});
+      CHECK_LAUNCH(who);
+      xp = cols;
+    }
+    rc = fpemu_gemm_wu_implicit_launch_(Gm, gout + n0 * K * P, xp, K, crs, P, nb, K * P, C * Hp * Wp, n0 == 0 ? 3 : 0, g.CB,
+                                        R, S, Hp * Wp, Wp, g.OW, stream);
+    if (rc != FPEMU_OK) return rc;
+  }
+  for (int64_t n0 = 0; !implicit && n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
     launch_cols_fp(in + n0 * C * H * W, cols, g, nb * crs, crs, Pp, stride, s);
     CHECK_LAUNCH(who);

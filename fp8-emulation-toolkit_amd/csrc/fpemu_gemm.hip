@@ -226,6 +226,14 @@ struct Batch {
   // wins, as torch.max) -- the amax pass of a per-tensor quantisation of C that follows (quantize_module_output,
   // reference qutils.py:607-609) is then already done: the values are in registers here.  The caller zeroes the word.
   uint32_t *amax;
+  // gemm_mfma16ws_kernel<..., WU = true> only (the convolution's weight update, stride 1): B is not a stored matrix but
+  // the zero-padded input planes of an image.  Row r = (cb, kj, ki, c2) (c2 fastest, wu_cb channels per block) is plane
+  // cb*wu_cb + c2 shifted by kj*wu_wp + ki; depth index p = oy*OW + ox (an output pixel) lies p + (p / OW) * wu_gap
+  // floats into the shifted plane (wu_gap = Wp - OW; p / OW = umulhi(p, wu_magic), exact for p < 2^20, OW < 2^12).
+  int wu_gap;
+  uint32_t wu_magic;
+  int wu_cb, wu_r, wu_s, wu_wp;
+  int64_t wu_plane;
 };
 
 __device__ __forceinline__ uint32_t abs_bits(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
@@ -1196,7 +1204,10 @@ __device__ __forceinline__ f32x4 ws_load_checked(const Operand &X, const float *
 
 // MODE 2: whole tiles of aligned operands (unchecked loads); 1: aligned operands, ragged edges (masked vector loads);
 // 0: anything (bounds-checked scalar loads).
-template <bool A_KCONT, bool B_KCONT, bool CHAIN, int MODE, int TS>
+// WU: B is the implicit gathered operand of a stride-1 weight update (Batch.wu_*): the same chain over the same products
+// as with the gathered matrix, read from the padded planes with 4-byte-aligned 16-byte loads (OW % 4 == 0: a vector of
+// four pixels never leaves its image row).
+template <bool A_KCONT, bool B_KCONT, bool CHAIN, int MODE, int TS, bool WU = false>
 __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Operand A, Operand B, float *C, int64_t ldc,
                                                                             float alpha, float beta, int tiles_m,
                                                                             int tiles_n, Batch bt) {
@@ -1256,8 +1267,19 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
         else r = r < N ? r : N - 4;
         pb_[h] = B_KCONT ? B.p + (int64_t)r * B.ld + k : B.p + (int64_t)k * B.ld + r;
         kb_[h] = k;
+        if constexpr (WU) {   // the row's shifted plane; the pixel's offset is added per tile (wu_src)
+          int rr = r;
+          const int c2 = rr % bt.wu_cb; rr /= bt.wu_cb;
+          const int ki = rr % bt.wu_s; rr /= bt.wu_s;
+          const int kj = rr % bt.wu_r, cb = rr / bt.wu_r;
+          pb_[h] = B.p + (int64_t)(cb * bt.wu_cb + c2) * bt.wu_plane + kj * bt.wu_wp + ki;
+        }
       }
     }
+    [[maybe_unused]] auto wu_src = [&](const float *rowp, const float *seg, int p) -> const float * {
+      const unsigned up = (unsigned)p;
+      return rowp + (seg - B.p) + (up + __umulhi(up, bt.wu_magic) * (unsigned)bt.wu_gap);
+    };
     // Fetches are UNCONDITIONAL: past the last tile the cursor stays where it is and the loads re-read that tile.
     // With a conditional fetch the compiler cannot count the loads in flight and waits for ALL of them (vmcnt(0))
     // before every LDS store -- the prefetch distance would be gone.
@@ -1281,11 +1303,13 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
         for (int h = 0; h < LNV; h++) {
           if (MODE == 2 || cur.k0 + SK <= K) {
             xa[h] = *reinterpret_cast<const f32x4 *>(pa_[h] + offa);
-            xb[h] = *reinterpret_cast<const f32x4 *>(pb_[h] + offb);
+            if constexpr (WU) xb[h] = *reinterpret_cast<const f32x4u *>(wu_src(pb_[h], cur.b, cur.k0 + kb_[h]));
+            else xb[h] = *reinterpret_cast<const f32x4 *>(pb_[h] + offb);
           } else {
             const bool ina = ka_[h] + cur.k0 < K, inb = kb_[h] + cur.k0 < K;
             xa[h] = *reinterpret_cast<const f32x4 *>(ina ? pa_[h] + offa : cur.a);
-            xb[h] = *reinterpret_cast<const f32x4 *>(inb ? pb_[h] + offb : cur.b);
+            if constexpr (WU) xb[h] = *reinterpret_cast<const f32x4u *>(wu_src(pb_[h], cur.b, inb ? cur.k0 + kb_[h] : 0));
+            else xb[h] = *reinterpret_cast<const f32x4 *>(inb ? pb_[h] + offb : cur.b);
             if (h == 0) out = 0u;
             out |= (ina ? 0u : 1u << h) | (inb ? 0u : 256u << h);
           }
@@ -1754,4 +1778,56 @@ extern "C" int fpemu_gemm_chain_start_launch_(float *C, const float *A, const fl
                      Batch{stride_a, stride_b, stride_c, kseg_stride_a, kseg_stride_b, (int)k_segments, start, init, (int)nstore,
                            amax},
                      stream);
+}
+
+// Internal to the library (fpemu_conv.hip): the weight update of a stride-1 convolution without its gathered operand.
+//   Gm[k][r] = chain (from +0 when start == 3, from Gm's values when start == 0) over images n, pixels p ascending of
+//              gout[n][k][p] * xp[n][plane(r)][(p / OW + kj(r)) * Wp + p % OW + ki(r)],   r = (cb, kj, ki, c2), c2 fastest
+// -- the products and the order of fpemu_gemm_chain_start_launch_ over cols_fp's matrix (the padded planes hold the zeros
+// cols_fp writes at padding taps), read in place by the small-tile chain kernel's loader waves.
+// fpemu_gemm_wu_implicit_ok_: whether a problem qualifies (the small-tile kernels, vector loads of gout, OW % 4 == 0).
+extern "C" int fpemu_gemm_wu_implicit_ok_(const float *gout, int64_t K, int64_t crs, int64_t P, int64_t OW, int64_t kseg_a,
+                                          int variant) {
+  if (!FPEMU_GEMM_WS || variant != 1 || K <= 0 || crs <= 0 || P <= 0 || OW <= 0) return 0;
+  if (fpemu_gemm_tile_edge_(K, crs, 1, variant) > 32) return 0;
+  if (!aligned16(gout) || (P % 4) || (kseg_a % 4) || (OW % 4)) return 0;
+  if (P >= ((int64_t)1 << 20) || OW >= 4096 || K > 0x7FFFFFFF || crs > 0x7FFFFFFF) return 0;
+  return 1;
+}
+
+extern "C" int fpemu_gemm_wu_implicit_launch_(float *Gm, const float *gout, const float *xp, int64_t K, int64_t crs,
+                                              int64_t P, int64_t images, int64_t kseg_a, int64_t kseg_b, int start,
+                                              int64_t CB, int64_t R, int64_t S, int64_t plane, int64_t Wp, int64_t OW,
+                                              void *stream) {
+  if (!fpemu_gemm_wu_implicit_ok_(gout, K, crs, P, OW, kseg_a, 1) || images < 1 || images > 0x7FFFFFFF ||
+      (start != 0 && start != 3) || !Gm || !xp || CB < 1 || R < 1 || S < 1 || crs % (CB * R * S) || Wp < OW) {
+    fpemu_set_error_("fpemu_gemm_wu_implicit_launch_: problem does not qualify");
+    return FPEMU_EINVAL;
+  }
+  const int tb = fpemu_gemm_tile_edge_(K, crs, 1, 1);
+  Operand a, b;
+  a.p = gout; a.ld = P; a.R = (int)K; a.K = (int)P; a.vec = 1; a.pad = -0.0f;
+  b.p = xp; b.ld = 0; b.R = (int)crs; b.K = (int)P; b.vec = 1; b.pad = 0.0f;
+  Batch bt{0, 0, 0, kseg_a, kseg_b, (int)images, start, nullptr, 0, nullptr};
+  bt.wu_gap = (int)(Wp - OW);
+  bt.wu_magic = (uint32_t)((((uint64_t)1) << 32) / (uint64_t)OW + 1u);
+  bt.wu_cb = (int)CB; bt.wu_r = (int)R; bt.wu_s = (int)S; bt.wu_wp = (int)Wp;
+  bt.wu_plane = plane;
+  const int tiles_m = (int)((K + tb - 1) / tb), tiles_n = (int)((crs + tb - 1) / tb);
+  const bool full = (K % tb == 0) && (crs % tb == 0) && (P % SK == 0);
+  const dim3 grid((unsigned)(tiles_m * tiles_n), 1u);
+  hipStream_t s = (hipStream_t)stream;
+  if (tb == 16) {
+    mfma_fn fn = full ? gemm_mfma16ws_kernel<true, true, true, 2, 16, true> : gemm_mfma16ws_kernel<true, true, true, 1, 16, true>;
+    hipLaunchKernelGGL(fn, grid, dim3(WsGeo<16>::NTHREADS), 0, s, a, b, Gm, crs, 1.0f, 0.0f, tiles_m, tiles_n, bt);
+  } else {
+    mfma_fn fn = full ? gemm_mfma16ws_kernel<true, true, true, 2, 32, true> : gemm_mfma16ws_kernel<true, true, true, 1, 32, true>;
+    hipLaunchKernelGGL(fn, grid, dim3(WsGeo<32>::NTHREADS), 0, s, a, b, Gm, crs, 1.0f, 0.0f, tiles_m, tiles_n, bt);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fpemu_set_error_(hipGetErrorString(e));
+    return (int)e;
+  }
+  return FPEMU_OK;
 }

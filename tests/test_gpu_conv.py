@@ -348,3 +348,60 @@ def test_strided_bp_takes_the_grouped_launch(hip):
     L.fpemu_gemm_tile_edge_.restype = ctypes.c_int
     edge = L.fpemu_gemm_tile_edge_(128, 400, 16, 1)
     assert edge >= 64 and 128 % edge == 0
+
+
+WU_IMPLICIT_CASES = [
+    (3, 64, 8, 8, 64, 3, 3, 1, 1),      # 16 x 16 tiles, 64 pixels per image: every k tile ragged (masked loads)
+    (2, 64, 16, 8, 64, 3, 3, 1, 1),     # 128 pixels per image: whole k tiles (unchecked loads)
+    (2, 64, 12, 12, 64, 1, 1, 1, 0),    # 1 x 1, no padding: the input planes are the operand
+    (2, 64, 14, 14, 64, 3, 3, 1, 0),    # no padding, 3 x 3: rows of 12 pixels in planes 14 wide
+    (2, 8, 10, 16, 24, 3, 3, 1, 1),     # 8-channel block, 72 x 24 results: ragged tiles in both directions
+    (2, 128, 8, 8, 128, 3, 3, 1, 1),    # 32 x 32 tiles
+    (2, 128, 16, 16, 128, 3, 3, 1, 1),  # 32 x 32 tiles, whole k tiles
+    (3, 64, 8, 12, 64, 5, 5, 1, 2),     # 5 x 5, padding 2
+    (2, 192, 12, 8, 64, 3, 3, 1, 1),    # three channel blocks
+]
+
+
+@pytest.mark.parametrize("case", WU_IMPLICIT_CASES)
+def test_conv_wu_implicit_operand(hip, case):
+    """Stride-1 weight update on the small-tile chain kernels: the loader waves read the (padded) input planes instead of
+    a gathered matrix (fpemu_gemm_wu_implicit_launch_).  Same chains as the oracle's, bit for bit -- with an Inf in the
+    input (a filler product of 0 x Inf would show as NaN), with chains of -0 products only, and chunk by chunk."""
+    N, C, H, W, K, R, S, st, pd = case
+    OH, OW = H + 2 * pd - R + 1, W + 2 * pd - S + 1
+    L = hip.lib()
+    rng = np.random.default_rng(sum(case) + 1)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    go = rng.standard_normal((N, K, OH, OW)).astype(np.float32)
+    tg = _t(go)
+    import ctypes
+
+    L.fpemu_gemm_wu_implicit_ok_.restype = ctypes.c_int
+    L.fpemu_gemm_wu_implicit_ok_.argtypes = [ctypes.c_void_p] + [ctypes.c_int64] * 5 + [ctypes.c_int]
+    assert L.fpemu_gemm_wu_implicit_ok_(tg.data_ptr(), K, C * R * S, OH * OW, OW, K * OH * OW, 1) == 1, "case must qualify"
+    want = orc.conv2d_wu(go, x, (R, S), st, pd, True)
+    gw = torch.full((K, C, R, S), 7.0, device=DEV)
+    hip.conv2d_wu_(gw, tg, _t(x), st, pd, 1)
+    assert_bits_equal(gw.cpu().numpy(), want, "implicit wu %s" % (case,))
+    # an Inf in the input, gout positive: every chain that meets it ends at +Inf, none at NaN
+    xi, gp = x.copy(), np.abs(go) + 0.5
+    xi[N - 1, C // 2, H // 2, W // 2] = np.inf
+    xi = np.abs(xi)
+    want = orc.conv2d_wu(gp, xi, (R, S), st, pd, True)
+    assert np.isinf(want).any() and not np.isnan(want).any()
+    hip.conv2d_wu_(gw, _t(gp), _t(xi), st, pd, 1)
+    assert_bits_equal(gw.cpu().numpy(), want, "implicit wu, Inf %s" % (case,))
+    # products of -0 only: chains from +0 stay +0
+    xz, gn = np.zeros_like(x), -np.abs(go) - 1.0
+    hip.conv2d_wu_(gw, _t(gn), _t(xz), st, pd, 1)
+    assert_bits_equal(gw.cpu().numpy(), orc.conv2d_wu(gn, xz, (R, S), st, pd, True), "implicit wu, -0 products")
+    # a workspace for one image: one launch per image, each continuing the chains of the one before
+    dims = (N, C, H, W, K, R, S, st, pd)
+    one = L.fpemu_conv2d_workspace_bytes(2, 1, *dims[1:])
+    ws = torch.empty(one // 4, device=DEV)
+    tx = _t(x)
+    assert L.fpemu_conv2d_wu_f32(gw.data_ptr(), tg.data_ptr(), tx.data_ptr(), *dims, 1, ws.data_ptr(), one, None) == 0, \
+        L.fpemu_last_error()
+    torch.cuda.synchronize()
+    assert_bits_equal(gw.cpu().numpy(), orc.conv2d_wu(go, x, (R, S), st, pd, True), "implicit wu, one image per chunk")
