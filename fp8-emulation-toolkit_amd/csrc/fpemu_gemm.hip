@@ -184,11 +184,14 @@ __device__ __forceinline__ void tile_store_one(float *T, int tid, int h, const f
 // XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch), so give each XCD a
 // contiguous run of tiles, and walk tiles in groups of 8 tile-rows so a run shares A rows / B columns
 // in that XCD's L2.  Bijective for any grid.
-__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int &tm, int &tn) {
-  const int nwg = tiles_m * tiles_n;
+__device__ __forceinline__ int xcd_run_index(int nwg) {   // block -> its place in its XCD's contiguous run of nwg work items
   const int orig = blockIdx.x;
   const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+}
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int &tm, int &tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int wg = xcd_run_index(nwg);
   constexpr int GROUP = 8;
   const int per_group = GROUP * tiles_n;
   const int g = wg / per_group;
@@ -1222,7 +1225,20 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
   __shared__ unsigned ws_stamps[256 * 8];  // stamps go to LDS (cheap, asynchronous) and are dumped once at the end
 #endif
   int tm, tn;
-  tile_of_block(tiles_m, tiles_n, tm, tn);
+  if (WU && bt.wu_cb % TS == 0) {
+    // Weight update read from the planes: the R*S taps of one group of TS channels are the SAME planes, shifted.  An
+    // XCD's run of tiles walks the taps fastest, then the tile rows, then the channel groups, so its L2 holds a few
+    // groups of planes and a few row blocks of gout instead of every XCD fetching all of both (C64 56 x 56 at batch 32:
+    // 401 MiB of L2 fills from the fabric for 49 MiB of operands in grid order).
+    const int taps = bt.wu_r * bt.wu_s, tpg = bt.wu_cb / TS;       // tiles per (channel block, tap)
+    const int wg = xcd_run_index(tiles_m * tiles_n);
+    const int tap = wg % taps, rest = wg / taps;
+    tm = rest % tiles_m;
+    const int pg = rest / tiles_m;                                  // (channel block, group of TS channels)
+    tn = ((pg / tpg) * taps + tap) * tpg + pg % tpg;
+  } else {
+    tile_of_block(tiles_m, tiles_n, tm, tn);
+  }
   const int m0 = tm * TS, n0 = tn * TS;
   const int K = A.K, M = A.R, N = B.R;
   const int kt = (K + SK - 1) / SK, total = kt * bt.nseg;
