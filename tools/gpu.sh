@@ -83,7 +83,7 @@ tools)      # every tools/ benchmark in turn -> gpurun_out/tools.txt
   run 120 python tools/latency.py
   run 240 python tools/bert_overhead.py
   run 300 python tools/model_overhead.py
-  [ -x tools/mfma_zero ] && run 60 tools/mfma_zero
+  if [ -x tools/mfma_zero ]; then run 60 tools/mfma_zero; fi
   ;;
 model)      # per-kernel GPU time of the emulated ResNet-50 training step (13 steps)
   stats gpurun_out/rn 400 python3 tools/model_overhead.py emu-only
