@@ -119,3 +119,24 @@ def test_header_is_plain_c_and_cxx():
             pytest.skip(cc + " not installed")
         r = subprocess.run([cc, "-Wall", "-Werror", "-fsyntax-only"] + args + [hdr], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_weight_update_operand_rule_without_gpu():
+    """Which weight updates read the input planes in place of a gathered operand (fpemu_gemm_wu_implicit_ok_: host
+    logic only): stride-1 shapes on the small-tile chain kernels whose rows of pixels are whole 16-byte vectors."""
+    L = ctypes.CDLL(SO)
+    ok = L.fpemu_gemm_wu_implicit_ok_
+    ok.restype = ctypes.c_int
+    ok.argtypes = [ctypes.c_void_p] + [ctypes.c_int64] * 5 + [ctypes.c_int]
+
+    def rule(K, C, R, S, OH, OW, ptr=4096, variant=1):
+        return ok(ptr, K, C * R * S, OH * OW, OW, K * OH * OW, variant)
+
+    assert rule(64, 64, 3, 3, 56, 56) == 1         # ResNet-50 layer1 3 x 3 (16 x 16 tiles)
+    assert rule(128, 128, 3, 3, 28, 28) == 1       # layer2 3 x 3 (32 x 32 tiles)
+    assert rule(64, 256, 1, 1, 56, 56) == 1        # 1 x 1
+    assert rule(256, 256, 3, 3, 14, 14) == 0       # 14 pixels per row: not whole vectors (and the large-tile kernel)
+    assert rule(512, 512, 3, 3, 8, 8) == 0         # 64 x 64 tiles: the gathered form
+    assert rule(64, 64, 3, 3, 56, 56, ptr=4100) == 0   # gout not 16-byte aligned
+    assert rule(64, 64, 3, 3, 56, 56, variant=0) == 0  # the separate-rounding variant runs on the VALU kernels
+    assert rule(64, 64, 3, 3, 1024, 1024) == 0     # pixel index past the exact range of the reciprocal multiply
