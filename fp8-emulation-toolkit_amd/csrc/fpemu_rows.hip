@@ -574,7 +574,14 @@ extern "C" int fpemu_rows_launch_(const void *in, void *out, uint64_t rows, uint
     // lane group: the smallest power of two covering the row's vectors, up to a wave; longer rows keep the
     // wave (<= 4 vectors per lane) or take the whole block; a lone row is spread over the block
     uint32_t lg = 0;
-    if (nv > 256u || ((force_block || rows == 1) && nv > 64u)) lg = 8;
+    // FPEMU_ROWS_WAVE_NV (tuning aid, tools/rows_quick.py): vectors per lane up to which a WAVE keeps a row (default 4)
+    static const uint32_t wave_nv_env = [] {
+      const char *e = getenv("FPEMU_ROWS_WAVE_NV");
+      const int v = e ? atoi(e) : 4;
+      return (uint32_t)(v < 1 ? 1 : v > 16 ? 16 : v);
+    }();
+    const uint32_t wave_nv = wave_nv_env < (uint32_t)reg_vecs(dtype) ? wave_nv_env : (uint32_t)reg_vecs(dtype);
+    if (nv > 64u * wave_nv || ((force_block || rows == 1) && nv > 64u)) lg = 8;
     else if (nv > 64u) lg = 6;
     else while ((1u << lg) < nv) lg++;
     const uint32_t per_lane = (nv + (1u << lg) - 1u) >> lg;
