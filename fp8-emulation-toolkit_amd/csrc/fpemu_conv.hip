@@ -578,6 +578,128 @@ __global__ __launch_bounds__(NT) void pad_planes(const float *__restrict__ x, fl
   }
 }
 
+// Strided forward convolution, implicit form: the zero-padded planes de-interleaved by phase of the stride,
+//   xp[plane][(py, px)][yh][xh] = x[plane][yh*st + py - ph][xh*st + px - pw], 0 outside   (Hh x Wh per phase)
+// so that every filter tap reads one phase plane with a stride-1 shift (fpemu_gemm.hip, ConvMap.st).  Optionally packs the
+// weights in the same launch (PACK, as pad_planes).  Four consecutive elements per thread, one 16-byte store.
+template <int PACK>
+__global__ __launch_bounds__(NT) void phase_planes(const float *__restrict__ x, float *__restrict__ xp, int64_t planes,
+                                                   int H, int W, int Hh, int Wh, int st, int ph, int pw,
+                                                   unsigned pad_blocks, PackJob job) {
+  if constexpr (PACK != 0) {
+    if (blockIdx.x >= pad_blocks) {  // uniform
+      const int64_t first = (int64_t)(blockIdx.x - pad_blocks) * NT + threadIdx.x, step = (int64_t)(gridDim.x - pad_blocks) * NT;
+      pack_w_fp_body(job.w, job.Wm, job.g, first, step);
+      return;
+    }
+  }
+  const int64_t PH = (int64_t)Hh * Wh, chan = PH * st * st, total = planes * chan;
+  for (int64_t i = ((int64_t)blockIdx.x * NT + threadIdx.x) * 4; i < total; i += (int64_t)pad_blocks * NT * 4) {
+    int64_t pl;
+    int rem;
+    if (total <= 0x7FFFFFFF) {  // uniform: 32-bit divisions
+      const uint32_t q = (uint32_t)i / (uint32_t)chan;
+      pl = q;
+      rem = (int)((uint32_t)i - q * (uint32_t)chan);
+    } else {
+      pl = i / chan;
+      rem = (int)(i - pl * chan);
+    }
+    int phase = rem / (int)PH;
+    rem -= phase * (int)PH;
+    int yh = rem / Wh, xh = rem - yh * Wh;
+    int py = phase / st, px = phase - py * st;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int sy = yh * st + py - ph, sx = xh * st + px - pw;
+      float v = 0.f;
+      if (i + e < total && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W)
+        v = x[(pl * H + sy) * (int64_t)W + sx];
+      o[e] = v;
+      if (++xh == Wh) {
+        xh = 0;
+        if (++yh == Hh) {
+          yh = 0;
+          if (++px == st) {
+            px = 0;
+            if (++py == st) { py = 0; pl++; }
+          }
+        }
+      }
+    }
+    if (i + 3 < total) {
+      *reinterpret_cast<f32x4 *>(xp + i) = o;
+    } else {
+      for (int e = 0; e < 4 && i + e < total; e++) xp[i + e] = o[e];
+    }
+  }
+}
+
+// phase_planes for stride 2, vectorised: a thread owns four consecutive columns of BOTH column phases of one row of one
+// row phase -- eight consecutive input floats (two 4-byte-aligned 16-byte loads), even ones to phase px = 0, odd ones to
+// px = 1, two 16-byte stores (4-byte aligned: the planes' pitch Wh is whatever the geometry gives).  The generic kernel
+// reads with a stride of two floats and decodes four indices per element: 29 us for the 51 MB of ResNet-50's C128
+// 56 x 56 layer at batch 32 against ~16 us here.
+typedef float f32x4s __attribute__((ext_vector_type(4), aligned(4)));
+template <int PACK>
+__global__ __launch_bounds__(NT) void phase_planes_s2(const float *__restrict__ x, float *__restrict__ xp, int64_t planes,
+                                                      int H, int W, int Hh, int Wh, int ph, int pw, unsigned pad_blocks,
+                                                      PackJob job) {
+  if constexpr (PACK != 0) {
+    if (blockIdx.x >= pad_blocks) {  // uniform
+      const int64_t first = (int64_t)(blockIdx.x - pad_blocks) * NT + threadIdx.x, step = (int64_t)(gridDim.x - pad_blocks) * NT;
+      pack_w_fp_body(job.w, job.Wm, job.g, first, step);
+      return;
+    }
+  }
+  const int nq = (Wh + 3) / 4;                       // groups of four columns per row
+  const int64_t PH = (int64_t)Hh * Wh;
+  const int64_t per_plane = (int64_t)2 * Hh * nq, total = planes * per_plane;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)pad_blocks * NT) {
+    int64_t pl;
+    int rem;
+    if (total <= 0x7FFFFFFF) {  // uniform: 32-bit divisions
+      const uint32_t q = (uint32_t)i / (uint32_t)per_plane;
+      pl = q;
+      rem = (int)((uint32_t)i - q * (uint32_t)per_plane);
+    } else {
+      pl = i / per_plane;
+      rem = (int)(i - pl * per_plane);
+    }
+    const int py = rem / (Hh * nq);
+    rem -= py * (Hh * nq);
+    const int yh = rem / nq, xq = rem - yh * nq;
+    const int sy = yh * 2 + py - ph, sx0 = xq * 8 - pw;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)sy < (unsigned)H) {
+      const float *row = x + (pl * H + sy) * (int64_t)W;
+      if (sx0 >= 0 && sx0 + 7 < W) {
+        const f32x4u a = *reinterpret_cast<const f32x4u *>(row + sx0), b = *reinterpret_cast<const f32x4u *>(row + sx0 + 4);
+        o0 = f32x4{a[0], a[2], b[0], b[2]};
+        o1 = f32x4{a[1], a[3], b[1], b[3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int s0 = sx0 + 2 * e, s1 = s0 + 1;
+          if ((unsigned)s0 < (unsigned)W) o0[e] = row[s0];
+          if ((unsigned)s1 < (unsigned)W) o1[e] = row[s1];
+        }
+      }
+    }
+    float *d0 = xp + (pl * 4 + py * 2) * PH + (int64_t)yh * Wh + xq * 4, *d1 = d0 + PH;
+    if (xq * 4 + 3 < Wh) {
+      *reinterpret_cast<f32x4s *>(d0) = o0;
+      *reinterpret_cast<f32x4s *>(d1) = o1;
+    } else {
+      for (int e = 0; e < 4 && xq * 4 + e < Wh; e++) {
+        d0[e] = o0[e];
+        d1[e] = o1[e];
+      }
+    }
+  }
+}
+
 // Backward-data for very few input channels (the network's first layer: C = 3, 7 x 7, stride 2).  As a GEMM this
 // is a 3-row problem over a K*R*S x H*W gathered operand (20 GB for ResNet-50's first layer at batch 32); here a
 // lane owns ONE input pixel and its <= 4 channel chains and walks the reference's order (ob, oj ascending,
@@ -922,6 +1044,9 @@ extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float 
                                        int64_t M, int64_t cblocks, int64_t R, int64_t S, int64_t plane, int64_t Wp,
                                        int64_t OH, int64_t OW, int reverse, uint32_t *amax, void *stream);
 extern "C" int fpemu_gemm_conv_tile_(int64_t M, int64_t nvalid, int64_t batch);
+extern "C" int fpemu_gemm_conv_phase_launch_(float *out, const float *Wm, const float *xp, const float *bias, int64_t batch,
+                                             int64_t M, int64_t cblocks, int64_t R, int64_t S, int64_t st, int64_t PH,
+                                             int64_t Wh, int64_t OH, int64_t OW, uint32_t *amax, void *stream);
 extern "C" int fpemu_gemm_wu_implicit_ok_(const float *gout, int64_t K, int64_t crs, int64_t P, int64_t OW, int64_t kseg_a,
                                           int variant);
 extern "C" int fpemu_gemm_wu_implicit_launch_(float *Gm, const float *gout, const float *xp, int64_t K, int64_t crs,
@@ -976,8 +1101,45 @@ int implicit_conv(const char *who, float *out, const float *src, const float *Wm
   return FPEMU_OK;
 }
 
+// Forward convolution with stride 2..4 over phase planes (see phase_planes).  Returns FPEMU_OK, an error, or 1 when the
+// workspace cannot hold one image's planes (nothing launched; the caller takes the gathered form).
+int implicit_conv_strided(const char *who, float *out, const float *src, const float *Wm, const float *bias, int64_t N,
+                          const Geo &g, float *xp, int64_t xp_floats, hipStream_t s, const PackJob &job, uint32_t *amax) {
+  const int64_t st = g.stride, Hp = g.H + 2 * g.pad, Wp = g.W + 2 * g.pad;
+  const int64_t Hh = (Hp + st - 1) / st, Wh = (Wp + st - 1) / st, PH = Hh * Wh, chan = st * st * PH;
+  const int64_t slack = 128 + (g.R / st + 2) * Wh + g.S + 4;   // read-ahead of the last tile past the last plane
+  int64_t chunk = N;
+  while (chunk > 1 && chunk * g.C * chan + slack > xp_floats) chunk = (chunk + 1) / 2;
+  if (chunk * g.C * chan + slack > xp_floats) return 1;
+  if (chunk > 65535) chunk = 65535;
+  const int64_t wtotal = g.K * g.C * g.R * g.S;
+  for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+    const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
+    const unsigned wb = n0 == 0 ? blocks_for(wtotal) : 0u;   // the weights ride on the first chunk's launch
+    if (st == 2) {
+      const unsigned pb = blocks_for(nb * g.C * 2 * Hh * ((Wh + 3) / 4));
+      hipLaunchKernelGGL(wb == 0 ? phase_planes_s2<0> : phase_planes_s2<1>, dim3(pb + wb), dim3(NT), 0, s,
+                         src + n0 * g.C * g.H * g.W, xp, nb * g.C, (int)g.H, (int)g.W, (int)Hh, (int)Wh, (int)g.pad, (int)g.pad,
+                         pb, job);
+    } else {
+      const unsigned pb = blocks_for((nb * g.C * chan + 3) / 4);
+      hipLaunchKernelGGL(wb == 0 ? phase_planes<0> : phase_planes<1>, dim3(pb + wb), dim3(NT), 0, s,
+                         src + n0 * g.C * g.H * g.W, xp, nb * g.C, (int)g.H, (int)g.W, (int)Hh, (int)Wh, (int)st, (int)g.pad,
+                         (int)g.pad, pb, job);
+    }
+    CHECK_LAUNCH(who);
+    const int rc = fpemu_gemm_conv_phase_launch_(out + n0 * g.K * g.OH * g.OW, Wm, xp, bias, nb, g.K, g.C / 64, g.R, g.S, st,
+                                                 PH, Wh, g.OH, g.OW, amax, (void *)s);
+    if (rc != 0) return fail(who, rc, hipGetErrorString((hipError_t)rc));
+  }
+  return FPEMU_OK;
+}
+
 #ifndef FPEMU_CONV_IMPLICIT
 #define FPEMU_CONV_IMPLICIT 1
+#endif
+#ifndef FPEMU_CONV_IMPLICIT_STRIDED
+#define FPEMU_CONV_IMPLICIT_STRIDED 1
 #endif
 
 }  // namespace
@@ -1020,6 +1182,15 @@ static int conv2d_fp_impl(const char *who, float *out, const float *in, const fl
     rc = implicit_conv(who, out, in, Wm, bias, N, C, H, W, K, R, S, pad, pad, g.OH, g.OW, 0, cols,
                        (int64_t)(ws_bytes / 4) - wf, s, 1, PackJob{w, Wm, g}, amax);
     if (rc != 1) return rc;  // 1: workspace too small for the padded planes (nothing launched) -> the gathered form below
+  }
+  // Strides 2..4 with a filter of more than one tap (ResNet-50's 3 x 3 stride-2 layers): phase planes instead of the
+  // gathered operand -- one read + one write of the input where the gather writes R*S / stride^2 of it and the GEMM
+  // reads that back.  (A 1 x 1 filter's gathered operand IS its one phase plane: nothing to gain.)
+  static const bool no_strided = getenv("FPEMU_CONV_FP_GATHER") != nullptr;   // tuning aid (tools/conv_bench.py)
+  if (FPEMU_CONV_IMPLICIT_STRIDED && !no_strided && variant == 1 && stride > 1 && stride <= 4 && R * S > 1 && C % 64 == 0 &&
+      K % 64 == 0) {
+    rc = implicit_conv_strided(who, out, in, Wm, bias, N, g, cols, (int64_t)(ws_bytes / 4) - wf, s, PackJob{w, Wm, g}, amax);
+    if (rc != 1) return rc;
   }
   if (chunk < 1) return fail(who, FPEMU_EINVAL, "workspace too small (fpemu_conv2d_workspace_bytes)");
   const int64_t kp = g.KP;  // chain length with its zero tail

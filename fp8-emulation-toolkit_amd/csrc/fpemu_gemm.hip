@@ -442,6 +442,12 @@ struct ConvMap {
   int S, R, Wp;       // filter taps per row / rows, padded row pitch
   int dk;             // +1: taps of a filter row walk right (forward); -1: left (backward-data: ki ascending = ox descending)
   int OW, P, nvalid;  // valid columns per output row, output pixels per channel (C's row pitch), OH * Wp
+  // Strided forward convolution (st > 1): the padded input is de-interleaved into its st * st phase planes, channel c of
+  // an image = [phase (py, px)][Hh][Wp] (Wp = the phase planes' pitch, PH = Hh * Wp floats each).  Tap (kj, ki) of output
+  // (oy, ox) reads padded pixel (oy*st + kj, ox*st + ki) = phase (kj % st, ki % st) at (oy + kj / st, ox + ki / st): a
+  // stride-1 walk again, the plane shifted by ((kj % st) * st + ki % st) * PH + (kj / st) * Wp + ki / st.
+  int st;             // 0 / 1: stride 1 (the three pointer steps above)
+  int64_t PH;
 };
 
 template <bool A_KCONT, bool B_KCONT, bool CHAIN, bool FULL, int TW, bool CONV>
@@ -484,10 +490,25 @@ __device__ __forceinline__ void gemm_mfma_body(Operand A, Operand B, float *C, i
   f32x4 pa[NV], pb[NV];
   const float *abase = A.p, *bbase = B.p;
   [[maybe_unused]] int wki = 0, wkj = 0;  // CONV: filter tap of the current k segment
+  [[maybe_unused]] int wri = 0, wqi = 0, wrj = 0, wqj = 0;  // CONV, st > 1: ki % st, ki / st, kj % st, kj / st
+  [[maybe_unused]] const float *cbase = B.p;                // CONV, st > 1: the current channel block's planes
   // next k segment: A by its segment stride; B by its segment stride, or (CONV) along the filter-tap walk
   auto next_segment = [&]() {
     abase += bt.ka;
     if constexpr (CONV) {
+      if (cm.st > 1) {  // uniform: phase planes (scalar counters, no division)
+        if (++wri == cm.st) { wri = 0; wqi++; }
+        if (++wki == cm.S) {
+          wki = 0; wri = 0; wqi = 0;
+          if (++wrj == cm.st) { wrj = 0; wqj++; }
+          if (++wkj == cm.R) {
+            wkj = 0; wrj = 0; wqj = 0;
+            cbase += bt.kb;
+          }
+        }
+        bbase = cbase + (int64_t)(wrj * cm.st + wri) * cm.PH + (int64_t)wqj * cm.Wp + wqi;
+        return;
+      }
       int64_t inc = cm.dk;
       if (++wki == cm.S) {
         wki = 0;
@@ -1690,7 +1711,32 @@ extern "C" int fpemu_gemm_conv_launch_(float *out, const float *Wm, const float 
   b.p = reverse ? xp + (S - 1) : xp; b.ld = plane; b.R = tiles_n * tb; b.K = 64; b.vec = 1; b.pad = 0.0f;
   Batch bt{0, cblocks * 64 * plane, M * OH * OW, 64, 64 * plane, (int)(cblocks * R * S)};
   bt.amax = amax;
-  ConvMap cm{bias, (int)S, (int)R, (int)Wp, reverse ? -1 : 1, (int)OW, (int)(OH * OW), (int)nvalid};
+  ConvMap cm{bias, (int)S, (int)R, (int)Wp, reverse ? -1 : 1, (int)OW, (int)(OH * OW), (int)nvalid, 1, 0};
+  const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)batch);
+  if (tb == 128)
+    hipLaunchKernelGGL(gemm_mfma_conv_kernel<2>, grid, dim3(NT), 0, (hipStream_t)stream, a, b, out, tiles_m, tiles_n, bt, cm);
+  else
+    hipLaunchKernelGGL(gemm_mfma_conv_kernel<1>, grid, dim3(NT), 0, (hipStream_t)stream, a, b, out, tiles_m, tiles_n, bt, cm);
+  return (int)hipGetLastError();
+}
+
+// Internal to the library (fpemu_conv.hip): the strided forward convolution over de-interleaved phase planes (ConvMap.st).
+//   out[b][m][oy][ox] = chain(bias[m]; for (cb, kj, ki, c2): Wm[m][((cb*R + kj)*S + ki)*64 + c2] *
+//                             xp[b][cb*64 + c2][(kj % st)*st + ki % st][oy + kj / st][ox + ki / st])
+// xp: per channel st*st phase planes of Hh x Wh floats (PH = Hh * Wh), readable for tile + (R/st + 1)*Wh + S floats past the
+// last plane.  M % 64 == 0.  The position grid is OH rows of Wh columns, of which the first OW are results.
+extern "C" int fpemu_gemm_conv_phase_launch_(float *out, const float *Wm, const float *xp, const float *bias, int64_t batch,
+                                             int64_t M, int64_t cblocks, int64_t R, int64_t S, int64_t st, int64_t PH,
+                                             int64_t Wh, int64_t OH, int64_t OW, uint32_t *amax, void *stream) {
+  const int64_t nvalid = OH * Wh, crs = cblocks * 64 * R * S, chan = st * st * PH;
+  const int tb = fpemu_gemm_conv_tile_(M, nvalid, batch);
+  const int tiles_m = (int)(M / tb), tiles_n = (int)((nvalid + tb - 1) / tb);
+  Operand a, b;
+  a.p = Wm; a.ld = crs; a.R = (int)M; a.K = 64; a.vec = 1; a.pad = -0.0f;
+  b.p = xp; b.ld = chan; b.R = tiles_n * tb; b.K = 64; b.vec = 1; b.pad = 0.0f;
+  Batch bt{0, cblocks * 64 * chan, M * OH * OW, 64, 64 * chan, (int)(cblocks * R * S)};
+  bt.amax = amax;
+  ConvMap cm{bias, (int)S, (int)R, (int)Wh, 1, (int)OW, (int)(OH * OW), (int)nvalid, (int)st, PH};
   const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)batch);
   if (tb == 128)
     hipLaunchKernelGGL(gemm_mfma_conv_kernel<2>, grid, dim3(NT), 0, (hipStream_t)stream, a, b, out, tiles_m, tiles_n, bt, cm);

@@ -76,6 +76,10 @@ def test_conv_vs_reference_fixture(hip, bname, variant, fused):
                                   # ... enough 64 x 64 tiles for the large-tile kernels: the four phases' GEMMs as ONE
                                   # grouped launch (test_strided_bp_takes_the_grouped_launch pins the tile edge)
                                   (16, 128, 40, 40, 64, 3, 3, 2, 1),
+                                  # strided forward over phase planes (64-channel blocks, more than one tap): odd sizes
+                                  # without padding, a 5 x 3 filter with padding 2, an even filter, stride 4 and stride 3
+                                  (2, 64, 11, 13, 64, 3, 3, 2, 0), (1, 128, 9, 10, 64, 5, 3, 2, 2), (2, 64, 12, 7, 64, 2, 2, 2, 1),
+                                  (1, 64, 17, 19, 64, 5, 5, 4, 2), (2, 64, 16, 16, 128, 3, 3, 3, 1),
                                   # weight update on the large-tile kernels with OH*OW = 196 not a multiple of 32: both
                                   # operands padded to 224 (the separate-rounding variant pads in most cases above)
                                   (3, 256, 14, 14, 256, 3, 3, 1, 1)])
