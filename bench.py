@@ -354,6 +354,25 @@ def main():
                                          "stores; median of 5 interleaved rounds x 10 launches, same buffers, same process"}
             step()  # y holds the cast again
 
+        # ---- placement: the same cast into the adjacent output (the timed workload) and into a separately allocated one ----
+        if rank == 0:
+            y_sep = torch.empty(n, dtype=torch.float32, device=dev)
+
+            def sep_step():
+                hip.cast_(x, y_sep, fmt, rm, scale=1.0, seed=1, offset=0, elem_base=rank * n)
+
+            pl = {"adjacent": [], "separate": []}
+            for _ in range(3):
+                pl["adjacent"].append(time_batch(step, launches=20, warm=3))
+                pl["separate"].append(time_batch(sep_step, launches=20, warm=3))
+            extras["placement"] = {
+                "GB/s": {k: round(8 * n / (sorted(v)[1] * 1e-3) / 1e9, 1) for k, v in pl.items()},
+                "separate_offset_bytes": y_sep.data_ptr() - x.data_ptr() - 4 * n,
+                "how": "output right behind the input in one allocation (what the timed region uses) against an output "
+                       "torch allocated on its own; median of 3 interleaved rounds x 20 launches, two events each "
+                       "(tools/offset_probe.py sweeps more placements)"}
+            del y_sep
+
         # ---- scaled path: amax (+ all-reduce(max) of one word over RCCL) + cast, 12 B/elem algorithmic ---------
         xf = torch.where(torch.isfinite(x), x, torch.full_like(x, 0.5))  # a NaN would make the scale NaN
         hxf = xf[:HEAD].cpu().numpy()

@@ -36,6 +36,7 @@ d = json.loads(open("gpurun_out/bench.log").read().strip().splitlines()[-1])
 print("value %.4g elem/s  ms %.4f  frac %.4f  events frac %.4f" % (d["value"], d["ms_per_step"], d["hbm_frac_of_peak"], d["roofline"]["frac"]))
 e = d["extras"]
 print("ceilings", e.get("ceilings"))
+print("placement", (e.get("placement") or {}).get("GB/s"))
 print("verified", e.get("verified"), "all:", e.get("all_verified"))
 for k, v in e.items():
     if isinstance(v, dict) and any(x in v for x in ("GB/s", "TFLOP/s", "GB/s_per_gpu", "TFLOP/s_effective")):
