@@ -1052,7 +1052,7 @@ extern "C" int fpemu_gemm_wu_implicit_ok_(const float *gout, int64_t K, int64_t 
 extern "C" int fpemu_gemm_wu_implicit_launch_(float *Gm, const float *gout, const float *xp, int64_t K, int64_t crs,
                                               int64_t P, int64_t images, int64_t kseg_a, int64_t kseg_b, int start,
                                               int64_t CB, int64_t R, int64_t S, int64_t plane, int64_t Wp, int64_t OW,
-                                              void *stream);
+                                              int64_t st, int64_t PH, void *stream);
 #ifndef FPEMU_CONV_WU_IMPLICIT
 #define FPEMU_CONV_WU_IMPLICIT 1
 #endif
@@ -1410,12 +1410,32 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
   // once (pad_planes, as the implicit forward), or the input as it is when there is no padding (1 x 1 filters).
   const int64_t Hp = H + 2 * pad, Wp = W + 2 * pad;
   static const bool no_implicit = getenv("FPEMU_CONV_WU_GATHER") != nullptr;   // tuning aid (tools/conv_bench.py)
-  const bool implicit = FPEMU_CONV_WU_IMPLICIT && !no_implicit && stride == 1 && N > 0 && Pp == P &&
-                        (pad == 0 || C * Hp * Wp <= per) &&
+  // Stride 2..4 with more than one tap: the same, over the phase planes of the padded input (phase_planes, as the strided
+  // forward): tap (kj, ki) is phase (kj % stride, ki % stride) shifted by (kj / stride, ki / stride).
+  const int64_t Hh = (Hp + stride - 1) / stride, Wh = (Wp + stride - 1) / stride, PH = Hh * Wh, chan = stride * stride * PH;
+  const bool phases = stride > 1;
+  const bool implicit = FPEMU_CONV_WU_IMPLICIT && !no_implicit && N > 0 && Pp == P &&
+                        (phases ? (stride <= 4 && R * S > 1 && C * chan <= per) : (pad == 0 || C * Hp * Wp <= per)) &&
                         fpemu_gemm_wu_implicit_ok_(gout, K, crs, P, g.OW, K * P, variant);
   for (int64_t n0 = 0; implicit && n0 < N; n0 += chunk) {
     const int64_t nb = (N - n0) < chunk ? (N - n0) : chunk;
     const float *xp = in + n0 * C * H * W;
+    if (phases) {
+      if (stride == 2) {
+        const unsigned pb = blocks_for(nb * C * 2 * Hh * ((Wh + 3) / 4));
+        hipLaunchKernelGGL(phase_planes_s2<0>, dim3(pb), dim3(NT), 0, s, xp, cols, nb * C, (int)H, (int)W, (int)Hh, (int)Wh, (int)pad,
+                           (int)pad, pb, PackJob{});
+      } else {
+        const unsigned pb = blocks_for((nb * C * chan + 3) / 4);
+        hipLaunchKernelGGL(phase_planes<0>, dim3(pb), dim3(NT), 0, s, xp, cols, nb * C, (int)H, (int)W, (int)Hh, (int)Wh, (int)stride,
+                           (int)pad, (int)pad, pb, PackJob{});
+      }
+      CHECK_LAUNCH(who);
+      rc = fpemu_gemm_wu_implicit_launch_(Gm, gout + n0 * K * P, cols, K, crs, P, nb, K * P, C * chan, n0 == 0 ? 3 : 0, g.CB, R, S,
+                                          chan, Wh, g.OW, stride, PH, stream);
+      if (rc != FPEMU_OK) return rc;
+      continue;
+    }
     if (pad != 0) {
       const unsigned pb = blocks_for((nb * C * Hp * Wp + 3) / 4);
       hipLaunchKernelGGL(pad_planes<0>, dim3(pb), dim3(NT), 0, s, xp, cols, nb * C, (int)H, (int)W, (int)Hp, (int)Wp, (int)pad,
@@ -1424,7 +1444,7 @@ int fpemu_conv2d_wu_f32(float *gw, const float *gout, const float *in, int64_t N
       xp = cols;
     }
     rc = fpemu_gemm_wu_implicit_launch_(Gm, gout + n0 * K * P, xp, K, crs, P, nb, K * P, C * Hp * Wp, n0 == 0 ? 3 : 0, g.CB,
-                                        R, S, Hp * Wp, Wp, g.OW, stream);
+                                        R, S, Hp * Wp, Wp, g.OW, 1, 0, stream);
     if (rc != FPEMU_OK) return rc;
   }
   for (int64_t n0 = 0; !implicit && n0 < N; n0 += chunk) {

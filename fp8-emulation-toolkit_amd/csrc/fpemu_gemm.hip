@@ -237,6 +237,11 @@ struct Batch {
   uint32_t wu_magic;
   int wu_cb, wu_r, wu_s, wu_wp;
   int64_t wu_plane;
+  // wu_st > 1: a strided weight update over the de-interleaved phase planes of fpemu_conv.hip (phase_planes): wu_plane is a
+  // CHANNEL's stride (wu_st^2 phase planes of wu_ph floats, pitch wu_wp) and tap (kj, ki) is phase (kj % st, ki % st)
+  // shifted by (kj / st) * wu_wp + ki / st.
+  int wu_st;
+  int64_t wu_ph;
 };
 
 __device__ __forceinline__ uint32_t abs_bits(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
@@ -1309,7 +1314,11 @@ __global__ __launch_bounds__(WsGeo<TS>::NTHREADS) void gemm_mfma16ws_kernel(Oper
           const int c2 = rr % bt.wu_cb; rr /= bt.wu_cb;
           const int ki = rr % bt.wu_s; rr /= bt.wu_s;
           const int kj = rr % bt.wu_r, cb = rr / bt.wu_r;
-          pb_[h] = B.p + (int64_t)(cb * bt.wu_cb + c2) * bt.wu_plane + kj * bt.wu_wp + ki;
+          if (bt.wu_st > 1)
+            pb_[h] = B.p + (int64_t)(cb * bt.wu_cb + c2) * bt.wu_plane +
+                     (int64_t)((kj % bt.wu_st) * bt.wu_st + ki % bt.wu_st) * bt.wu_ph + (kj / bt.wu_st) * bt.wu_wp + ki / bt.wu_st;
+          else
+            pb_[h] = B.p + (int64_t)(cb * bt.wu_cb + c2) * bt.wu_plane + kj * bt.wu_wp + ki;
         }
       }
     }
@@ -1860,9 +1869,11 @@ extern "C" int fpemu_gemm_wu_implicit_ok_(const float *gout, int64_t K, int64_t 
 extern "C" int fpemu_gemm_wu_implicit_launch_(float *Gm, const float *gout, const float *xp, int64_t K, int64_t crs,
                                               int64_t P, int64_t images, int64_t kseg_a, int64_t kseg_b, int start,
                                               int64_t CB, int64_t R, int64_t S, int64_t plane, int64_t Wp, int64_t OW,
-                                              void *stream) {
+                                              int64_t st, int64_t PH, void *stream) {
+  // st > 1: `plane` is a channel's stride over its st * st phase planes of PH floats each (pitch Wp), see Batch.wu_st
   if (!fpemu_gemm_wu_implicit_ok_(gout, K, crs, P, OW, kseg_a, 1) || images < 1 || images > 0x7FFFFFFF ||
-      (start != 0 && start != 3) || !Gm || !xp || CB < 1 || R < 1 || S < 1 || crs % (CB * R * S) || Wp < OW) {
+      (start != 0 && start != 3) || !Gm || !xp || CB < 1 || R < 1 || S < 1 || crs % (CB * R * S) || Wp < OW || st < 1 ||
+      st > 4) {
     fpemu_set_error_("fpemu_gemm_wu_implicit_launch_: problem does not qualify");
     return FPEMU_EINVAL;
   }
@@ -1875,6 +1886,8 @@ extern "C" int fpemu_gemm_wu_implicit_launch_(float *Gm, const float *gout, cons
   bt.wu_magic = (uint32_t)((((uint64_t)1) << 32) / (uint64_t)OW + 1u);
   bt.wu_cb = (int)CB; bt.wu_r = (int)R; bt.wu_s = (int)S; bt.wu_wp = (int)Wp;
   bt.wu_plane = plane;
+  bt.wu_st = (int)st;
+  bt.wu_ph = PH;
   const int tiles_m = (int)((K + tb - 1) / tb), tiles_n = (int)((crs + tb - 1) / tb);
   const bool full = (K % tb == 0) && (crs % tb == 0) && (P % SK == 0);
   const dim3 grid((unsigned)(tiles_m * tiles_n), 1u);

@@ -364,16 +364,19 @@ WU_IMPLICIT_CASES = [
     (2, 128, 16, 16, 128, 3, 3, 1, 1),  # 32 x 32 tiles, whole k tiles
     (3, 64, 8, 12, 64, 5, 5, 1, 2),     # 5 x 5, padding 2
     (2, 192, 12, 8, 64, 3, 3, 1, 1),    # three channel blocks
+    # strided: the same loader over the de-interleaved phase planes of the padded input (strides 2, 3, 4)
+    (2, 64, 16, 16, 64, 3, 3, 2, 1), (2, 128, 16, 24, 128, 3, 3, 2, 1), (2, 64, 16, 22, 64, 3, 3, 3, 1),
+    (1, 64, 17, 31, 64, 5, 5, 4, 2), (3, 64, 9, 16, 64, 2, 2, 2, 0),
 ]
 
 
 @pytest.mark.parametrize("case", WU_IMPLICIT_CASES)
 def test_conv_wu_implicit_operand(hip, case):
-    """Stride-1 weight update on the small-tile chain kernels: the loader waves read the (padded) input planes instead of
-    a gathered matrix (fpemu_gemm_wu_implicit_launch_).  Same chains as the oracle's, bit for bit -- with an Inf in the
+    """Weight update on the small-tile chain kernels: the loader waves read the (padded) input planes -- for strides 2-4
+    their de-interleaved phase planes -- instead of a gathered matrix (fpemu_gemm_wu_implicit_launch_).  Same chains as the oracle's, bit for bit -- with an Inf in the
     input (a filler product of 0 x Inf would show as NaN), with chains of -0 products only, and chunk by chunk."""
     N, C, H, W, K, R, S, st, pd = case
-    OH, OW = H + 2 * pd - R + 1, W + 2 * pd - S + 1
+    OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
     L = hip.lib()
     rng = np.random.default_rng(sum(case) + 1)
     x = rng.standard_normal((N, C, H, W)).astype(np.float32)
