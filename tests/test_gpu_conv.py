@@ -412,3 +412,37 @@ def test_conv_wu_implicit_operand(hip, case):
         L.fpemu_last_error()
     torch.cuda.synchronize()
     assert_bits_equal(gw.cpu().numpy(), orc.conv2d_wu(go, x, (R, S), st, pd, True), "implicit wu, one image per chunk")
+
+
+@pytest.mark.parametrize("case", [(5, 64, 12, 12, 64, 3, 3, 2, 1), (3, 64, 12, 12, 64, 2, 2, 2, 1), (3, 128, 9, 11, 64, 3, 3, 3, 0)])
+def test_strided_conv_small_workspaces(hip, case):
+    """Strided forward / weight update over phase planes with the full workspace, with one that holds a single image
+    (chunked: the weight update's chains continue from launch to launch) and -- 2 x 2 filters, whose phase planes are
+    larger than their gathered operand -- with one the phase planes do not fit in (the gathered form takes over)."""
+    N, C, H, W, K, R, S, st, pd = case
+    OH, OW = (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1
+    rng = np.random.default_rng(sum(case) + 3)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((K, C, R, S)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    go = rng.standard_normal((N, K, OH, OW)).astype(np.float32)
+    L = hip.lib()
+    want_fp = orc.conv2d_fp(x, w, b, st, pd, True)
+    want_wu = orc.conv2d_wu(go, x, (R, S), st, pd, True)
+    tx, tw, tb, tg = _t(x), _t(w), _t(b), _t(go)
+    for kind, full, one in ((0, L.fpemu_conv2d_workspace_bytes(0, *case), L.fpemu_conv2d_workspace_bytes(0, 1, *case[1:])),
+                            (2, L.fpemu_conv2d_workspace_bytes(2, *case), L.fpemu_conv2d_workspace_bytes(2, 1, *case[1:]))):
+        for nbytes in (full, one):
+            ws = torch.empty(nbytes // 4 + 4, device=DEV)
+            if kind == 0:
+                y = torch.empty(N, K, OH, OW, device=DEV)
+                assert L.fpemu_conv2d_fp_f32(y.data_ptr(), tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), *case, 1, ws.data_ptr(),
+                                             nbytes, None) == 0, L.fpemu_last_error()
+                torch.cuda.synchronize()
+                assert_bits_equal(y.cpu().numpy(), want_fp, "strided fp %s, workspace %d" % (case, nbytes))
+            else:
+                gw = torch.empty(K, C, R, S, device=DEV)
+                assert L.fpemu_conv2d_wu_f32(gw.data_ptr(), tg.data_ptr(), tx.data_ptr(), *case, 1, ws.data_ptr(), nbytes,
+                                             None) == 0, L.fpemu_last_error()
+                torch.cuda.synchronize()
+                assert_bits_equal(gw.cpu().numpy(), want_wu, "strided wu %s, workspace %d" % (case, nbytes))
