@@ -1,6 +1,6 @@
 """The randomised parity tests of tests/test_gpu_fuzz.py over OTHER seeds than the committed ones (a one-off campaign on a
 GPU box, not part of the suite): every `np.random.default_rng(seed)` of a round draws from seed + 1000003 * round.
-usage: fuzz_campaign.py [rounds] [first_round]"""
+usage: fuzz_campaign.py [rounds] [first_round] [substring of the test names to run]"""
 import os
 import sys
 import time
@@ -18,7 +18,8 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 hip.lib()
 orig = np.random.default_rng
-tests = [getattr(fz, n) for n in dir(fz) if n.startswith("test_")]
+only = sys.argv[3] if len(sys.argv) > 3 else ""
+tests = [getattr(fz, n) for n in dir(fz) if n.startswith("test_") and only in n]
 for rnd in range(first, first + rounds):
     np.random.default_rng = lambda s=None, _r=rnd: orig((0 if s is None else int(s)) + 1000003 * _r)
     for t in tests:
