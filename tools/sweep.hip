@@ -297,6 +297,16 @@ int main(int argc, char **argv) {
   add("E3 cast pipe B256 g2048 store-first", k_pipe<256, false, true>, 256, 2048, 0);
   add("E3 cast pipe B128 g8192 load-first", k_pipe<128, true, true>, 128, 8192, 0);
   add("E3 cast pipe B128 g32768 load-first", k_pipe<128, true, true>, 128, 32768, 0);
+  // occupancy caps through dynamic LDS (160 KiB per CU): workgroups of 128 threads resident per CU = 12 / 8 / 6 / 4 / 2
+  if (getenv("SWEEP_OCC")) {
+    add("pol B128, 13 KiB LDS (12 groups per CU)", k_pol<1, 4, true, 128>, 128, noloop(128, 1), 13 * 1024);
+    add("pol B128, 20 KiB LDS (8 per CU)", k_pol<1, 4, true, 128>, 128, noloop(128, 1), 20 * 1024);
+    add("pol B128, 26 KiB LDS (6 per CU)", k_pol<1, 4, true, 128>, 128, noloop(128, 1), 26 * 1024);
+    add("pol B128, 40 KiB LDS (4 per CU)", k_pol<1, 4, true, 128>, 128, noloop(128, 1), 40 * 1024);
+    add("pol B128, 80 KiB LDS (2 per CU)", k_pol<1, 4, true, 128>, 128, noloop(128, 1), 80 * 1024);
+    add("pol B256, 40 KiB LDS (4 per CU)", k_pol<1, 4, true>, 256, g1, 40 * 1024);
+    add("pol B64, 10 KiB LDS (16 per CU)", k_pol<1, 4, true, 64>, 64, noloop(64, 1), 10 * 1024);
+  }
   add("READ-only nt U1 (x2 scale)", k_read<true>, 256, g1, 0);
   add("amax B256 VPT8 cond (x2 scale)", k_amax<256, 8, true>, 256, noloop(256, 8), 0);
   hipEvent_t e0, e1;
@@ -337,10 +347,10 @@ int main(int argc, char **argv) {
       // left dirty lines in L2 / Infinity Cache that this one would pay for, or a clean cache that
       // absorbs this one's stores for free), then REPS back-to-back timed launches.
       CK(hipMemsetAsync(out, 0, 64, 0));
-      hipLaunchKernelGGL(v.fn, dim3(v.grid), dim3(v.block), 0, 0, in, out, nvec, 1.0f, 1.0f);
+      hipLaunchKernelGGL(v.fn, dim3(v.grid), dim3(v.block), v.vec_per_block_iter, 0, in, out, nvec, 1.0f, 1.0f);  // vec_per_block_iter doubles as the dynamic LDS size (occupancy caps)
       CK(hipEventRecord(e0, 0));
       for (int k = 0; k < REPS; k++)
-        hipLaunchKernelGGL(v.fn, dim3(v.grid), dim3(v.block), 0, 0, in, out, nvec, 1.0f, 1.0f);
+        hipLaunchKernelGGL(v.fn, dim3(v.grid), dim3(v.block), v.vec_per_block_iter, 0, in, out, nvec, 1.0f, 1.0f);  // vec_per_block_iter doubles as the dynamic LDS size (occupancy caps)
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
       float ms;
